@@ -1,0 +1,92 @@
+"""ctypes binding of libdismember_hip.so (the C ABI of include/dismember_hip.h).
+
+There is no Python or CPU implementation behind this module: if the shared
+library is missing or no HIP device is usable, calls fail loudly.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libdismember_hip.so")
+SRC_DIR = os.path.join(_DIR, "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(_DIR), "include")
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+u8p = C.POINTER(C.c_uint8)
+
+
+class SearchOpts(C.Structure):
+    _fields_ = [("beam", C.c_int), ("topk", C.c_int), ("use_mask", C.c_int), ("widen_consumed", C.c_int)]
+
+
+# name -> (restype, argtypes); also the list of symbols include/dismember_hip.h declares
+SIGNATURES = {
+    "dm_version": (C.c_int, []),
+    "dm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dm_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "dm_destroy": (C.c_int, [C.c_void_p]),
+    "dm_last_error": (C.c_char_p, [C.c_void_p]),
+    "dm_synchronize": (C.c_int, [C.c_void_p]),
+    "dm_load_tree_tdm": (C.c_int, [C.c_void_p, i32p, i32p, u8p, C.c_int64, C.c_int]),
+    "dm_load_id_maps": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64]),
+    "dm_tdm_id_to_code": (C.c_int, [C.c_void_p, i32p, C.c_int, i32p, i32p, C.POINTER(C.c_int)]),
+    "dm_level_start": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dm_load_weights_din": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
+    "dm_din_forward": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "dm_tdm_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.POINTER(SearchOpts), i64p, i32p, i32p,
+                                     f32p, i32p]),
+    "dm_tdm_beam_search_trace": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.POINTER(SearchOpts), i32p, f32p,
+                                           i32p, C.c_int, i32p, f32p, i32p]),
+    "dm_otm_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
+    "dm_tdm_bruteforce_topk": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
+    "dm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dm_tdm_beam_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(SearchOpts),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
+    "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dm_last_scored_rows": (C.c_int, [C.c_void_p, i64p]),
+}
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))]
+    srcs.append(os.path.join(INCLUDE_DIR, "dismember_hip.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+           os.path.join(SRC_DIR, "dm_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdismember_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

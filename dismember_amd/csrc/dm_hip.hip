@@ -1,0 +1,799 @@
+// libdismember_hip.so — MI355X (gfx950) implementation of dismember's tree beam-search
+// retrieval hot path behind the C ABI of include/dismember_hip.h.
+//
+// No CPU fallback lives here: every entry point that computes launches HIP kernels.
+#include "../../include/dismember_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "beam_kernel.hip.inc"
+
+#define DM_VERSION 100
+
+// ------------------------------------------------------------------ context
+struct dm_ctx {
+  int device = 0;
+  int n_cu = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // tree (codeNodeMap as bitmaps + dense node-id array)
+  bool tree_loaded = false, ids_loaded = false, leaves_at_max_only = true;
+  int max_level = 0;
+  int64_t n_slots = 0, n_leaf_nodes = 0;
+  uint32_t *d_exists = nullptr, *d_leaf = nullptr;
+  int32_t *d_node_id = nullptr, *d_id_to_code = nullptr, *d_leaf_codes = nullptr;
+  int32_t non_leaf_offset = -1, max_code = -1;
+  std::vector<int32_t> h_id_to_code;
+  // weights
+  bool w_loaded = false;
+  int dtype = DM_F32, embed = 0;
+  int64_t num_index = 0;
+  void *d_compact = nullptr;   // as loaded (float or double)
+  float *d_emb32 = nullptr;    // f32 table (aliases d_compact for DM_F32)
+  bool emb32_owned = false;
+  f32x4 *d_wfrag = nullptr;
+  float *d_att_wT = nullptr, *d_w1bT = nullptr, *d_b1 = nullptr, *d_w2 = nullptr;
+  float b2 = 0.f;
+  void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
+  // measurement
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  unsigned long long *d_rows = nullptr;
+  int64_t last_rows = 0;
+  // cached search workspace
+  void *d_ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      char b_[512];                                                                       \
+      snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      (h)->err = b_;                                                                      \
+      return DM_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+static int fail(dm_ctx *h, int code, const std::string &msg) {
+  if (h) h->err = msg; else g_create_err = msg;
+  return code;
+}
+
+// ------------------------------------------------------------ small kernels
+__global__ void dm_f64_to_f32_kernel(const double *in, float *out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = (float)in[i];
+}
+
+__global__ void dm_pad_rowmask_kernel(const int32_t *pad_flat, int64_t n_pad, int L, unsigned *rowmask) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) {
+    int64_t idx = pad_flat[i];
+    atomicOr(&rowmask[idx / L], 1u << (idx % L));
+  }
+}
+
+// General DIN forward, one wave per row, any (code, history, mask) per row:
+// Module.forward of tdm/.../model/DIN.scala:18-42 for arbitrary batches (the beam kernels
+// use the per-user restructured form instead).  T = float | double.
+template <typename T>
+struct DinFwdParams {
+  const T *emb, *att_wT, *l1T, *b1, *w2;  // att_wT [E k][E o], l1T [2E k][E o]
+  T b2;
+  int E, L;
+  int64_t B;
+  const int32_t *codes, *seqs;
+  const unsigned *rowmask;
+  T *out;
+};
+
+template <typename T>
+__device__ __forceinline__ T dm_wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dm_din_forward_kernel(DinFwdParams<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_fw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int E = p.E, L = p.L;
+  T *q = (T *)smem_fw + (size_t)wave * (3 * E + 32);
+  T *comb = q + E, *att = comb + E, *sc = att + E;
+  const T scale = (T)(1.0 / sqrt((double)E));
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.B; row += (int64_t)gridDim.x * 4) {
+    const int32_t code = p.codes[row];
+    for (int e = lane; e < E; e += 64) q[e] = code >= 0 ? p.emb[(int64_t)code * E + e] : (T)0;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned mask = p.rowmask ? p.rowmask[row] : 0u;
+    for (int j = 0; j < L; j++) {
+      const int32_t c = p.seqs[row * L + j];
+      T part = 0;
+      if (c >= 0)
+        for (int e = lane; e < E; e += 64) part += q[e] * p.emb[(int64_t)c * E + e];
+      T s = dm_wave_sum(part) * scale;
+      if ((mask >> j) & 1u) s = (T)(-FLT_MAX);
+      if (lane == 0) sc[j] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T mx = sc[0];
+    for (int j = 1; j < L; j++) mx = sc[j] > mx ? sc[j] : mx;
+    T sum;
+    sum = 0;
+    for (int j = 0; j < L; j++) {
+      T e = sizeof(T) == 4 ? (T)expf((float)(sc[j] - mx)) : (T)exp((double)(sc[j] - mx));
+      sum += e;
+    }
+    const T inv = (T)1 / sum;
+    for (int e = lane; e < E; e += 64) comb[e] = 0;
+    for (int j = 0; j < L; j++) {
+      const int32_t c = p.seqs[row * L + j];
+      T ex = sizeof(T) == 4 ? (T)expf((float)(sc[j] - mx)) : (T)exp((double)(sc[j] - mx));
+      T pj = ex * inv;
+      if (c >= 0)
+        for (int e = lane; e < E; e += 64) comb[e] += pj * p.emb[(int64_t)c * E + e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int o = lane; o < E; o += 64) {
+      T a = 0;
+      for (int k = 0; k < E; k++) a += comb[k] * p.att_wT[(size_t)k * E + o];
+      att[o] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T part = 0;
+    for (int o = lane; o < E; o += 64) {
+      T hsum = 0;
+      for (int k = 0; k < E; k++) hsum += q[k] * p.l1T[(size_t)k * E + o];
+      for (int k = 0; k < E; k++) hsum += att[k] * p.l1T[(size_t)(E + k) * E + o];
+      hsum += p.b1[o];
+      hsum = hsum > 0 ? hsum : (T)0;
+      part += hsum * p.w2[o];
+    }
+    T logit = dm_wave_sum(part) + p.b2;
+    if (lane == 0) p.out[row] = logit;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------ helpers
+static int dm_alloc(dm_ctx *h, void **p, size_t bytes) {
+  HIPCHK(h, hipMalloc(p, bytes ? bytes : 16));
+  return DM_OK;
+}
+#define ALLOC(h, ptr, bytes)                                   \
+  do {                                                         \
+    int rc_ = dm_alloc((h), (void **)&(ptr), (bytes));         \
+    if (rc_ != DM_OK) return rc_;                              \
+  } while (0)
+static void dm_free_ptr(void *p) { if (p) (void)hipFree(p); }
+
+static int level_start_int(int candidate_num, int *start, int *level) {
+  if (candidate_num <= 0) return DM_ERR_INVALID;
+  int lv = 0;
+  while ((2 << lv) <= candidate_num) lv++;   // floor(log2)
+  *level = lv;
+  *start = (1 << lv) - 1;
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+// (every dm_* below is declared extern "C" by include/dismember_hip.h)
+
+int dm_version(void) { return DM_VERSION; }
+
+int dm_device_count(int *count) {
+  if (!count) return DM_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; g_create_err = hipGetErrorString(e); return DM_ERR_HIP; }
+  *count = n;
+  return DM_OK;
+}
+
+const char *dm_last_error(dm_handle_t h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int dm_create(int device_id, dm_handle_t *out) {
+  if (!out) return fail(nullptr, DM_ERR_INVALID, "dm_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, DM_ERR_HIP, std::string("dm_create: no HIP device available (") +
+                                         (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                                         "); this library has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, DM_ERR_INVALID, "dm_create: device_id out of range");
+  dm_ctx *h = new dm_ctx();
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipSetDevice failed"); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipGetDeviceProperties failed"); }
+  h->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipStreamCreate failed"); }
+  if (hipMalloc((void **)&h->d_rows, 8) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
+  (void)hipMemset(h->d_rows, 0, 8);
+  *out = h;
+  return DM_OK;
+}
+
+static void free_tree(dm_ctx *h) {
+  dm_free_ptr(h->d_exists); dm_free_ptr(h->d_leaf); dm_free_ptr(h->d_node_id); dm_free_ptr(h->d_leaf_codes);
+  h->d_exists = h->d_leaf = nullptr; h->d_node_id = h->d_leaf_codes = nullptr; h->tree_loaded = false;
+}
+static void free_weights(dm_ctx *h) {
+  if (h->emb32_owned) dm_free_ptr(h->d_emb32);
+  dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_att_wT); dm_free_ptr(h->d_w1bT);
+  dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
+  h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
+  h->d_att_wT = h->d_w1bT = h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
+}
+
+int dm_destroy(dm_handle_t h) {
+  if (!h) return DM_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_tree(h); free_weights(h);
+  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_ws);
+  for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return DM_OK;
+}
+
+int dm_synchronize(dm_handle_t h) {
+  if (!h) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DM_OK;
+}
+
+int dm_level_start(int candidate_num, int *start_code, int *level) {
+  if (!start_code || !level) return DM_ERR_INVALID;
+  return level_start_int(candidate_num, start_code, level);
+}
+
+int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_ids, const uint8_t *is_leaf,
+                     int64_t n_nodes, int max_level) {
+  if (!h) return DM_ERR_INVALID;
+  if (!codes || !node_ids || !is_leaf || n_nodes <= 0 || max_level < 0 || max_level > 30)
+    return fail(h, DM_ERR_INVALID, "dm_load_tree_tdm: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  int64_t mc = -1;
+  for (int64_t i = 0; i < n_nodes; i++) {
+    if (codes[i] < 0) return fail(h, DM_ERR_INVALID, "dm_load_tree_tdm: negative code");
+    if (codes[i] > mc) mc = codes[i];
+  }
+  const int64_t n_slots = mc + 1;
+  const int64_t words = (n_slots + 31) / 32 + 1;
+  std::vector<uint32_t> ex(words, 0), lf(words, 0);
+  std::vector<int32_t> nid(n_slots, 0), leaf_codes;
+  bool at_max_only = true;
+  const int64_t first_max = ((int64_t)1 << max_level) - 1;
+  for (int64_t i = 0; i < n_nodes; i++) {
+    int64_t c = codes[i];
+    ex[c >> 5] |= 1u << (c & 31);
+    nid[c] = node_ids[i];
+    if (is_leaf[i]) { lf[c >> 5] |= 1u << (c & 31); leaf_codes.push_back((int32_t)c); if (c < first_max) at_max_only = false; }
+  }
+  free_tree(h);
+  ALLOC(h, h->d_exists, words * 4);
+  ALLOC(h, h->d_leaf, words * 4);
+  ALLOC(h, h->d_node_id, n_slots * 4);
+  ALLOC(h, h->d_leaf_codes, leaf_codes.size() * 4);
+  HIPCHK(h, hipMemcpy(h->d_exists, ex.data(), words * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_leaf, lf.data(), words * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_node_id, nid.data(), n_slots * 4, hipMemcpyHostToDevice));
+  if (!leaf_codes.empty())
+    HIPCHK(h, hipMemcpy(h->d_leaf_codes, leaf_codes.data(), leaf_codes.size() * 4, hipMemcpyHostToDevice));
+  h->n_slots = n_slots; h->n_leaf_nodes = (int64_t)leaf_codes.size(); h->max_level = max_level;
+  h->leaves_at_max_only = at_max_only; h->tree_loaded = true;
+  return DM_OK;
+}
+
+int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *leaf_codes, int64_t n) {
+  if (!h) return DM_ERR_INVALID;
+  if (!leaf_item_ids || !leaf_codes || n <= 0) return fail(h, DM_ERR_INVALID, "dm_load_id_maps: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  int32_t mid = -1, mcode = -1;
+  for (int64_t i = 0; i < n; i++) {
+    if (leaf_item_ids[i] > mid) mid = leaf_item_ids[i];
+    if (leaf_codes[i] > mcode) mcode = leaf_codes[i];
+  }
+  if (mid < 0) return fail(h, DM_ERR_INVALID, "dm_load_id_maps: no non-negative item id");
+  h->non_leaf_offset = mid + 1;   // DistTree.scala:35
+  h->max_code = mcode;            // DistTree.scala:36
+  h->h_id_to_code.assign((size_t)h->non_leaf_offset, -1);
+  for (int64_t i = 0; i < n; i++)
+    if (leaf_item_ids[i] >= 0) h->h_id_to_code[leaf_item_ids[i]] = leaf_codes[i];
+  dm_free_ptr(h->d_id_to_code); h->d_id_to_code = nullptr;
+  ALLOC(h, h->d_id_to_code, h->h_id_to_code.size() * 4);
+  HIPCHK(h, hipMemcpy(h->d_id_to_code, h->h_id_to_code.data(), h->h_id_to_code.size() * 4, hipMemcpyHostToDevice));
+  h->ids_loaded = true;
+  return DM_OK;
+}
+
+int dm_tdm_id_to_code(dm_handle_t h, const int32_t *item_ids, int n, int32_t *codes, int32_t *mask_pos, int *n_mask) {
+  if (!h) return DM_ERR_INVALID;
+  if (!h->ids_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_id_to_code: id maps not loaded");
+  if (!item_ids || !codes || !mask_pos || !n_mask || n < 0) return fail(h, DM_ERR_INVALID, "dm_tdm_id_to_code: bad arguments");
+  int nm = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t id = item_ids[i];
+    if (id == 0) { mask_pos[nm++] = i; codes[i] = -1; }
+    else if (id < h->non_leaf_offset && id >= 0 && h->h_id_to_code[id] >= 0) codes[i] = h->h_id_to_code[id];
+    else {
+      int32_t t = (int32_t)((uint32_t)id - (uint32_t)h->non_leaf_offset);
+      if (t > h->max_code) { mask_pos[nm++] = i; codes[i] = -1; } else codes[i] = t;
+    }
+  }
+  *n_mask = nm;
+  return DM_OK;
+}
+
+template <typename T>
+static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64_t n_elems) {
+  const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
+  if (need != n_elems) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: n_elems does not match the DIN layout for (E, num_index)");
+  const T *att_w = w + num_index * E, *l1_w = att_w + (int64_t)E * E, *l1_b = l1_w + (int64_t)E * 2 * E;
+  const T *l2_w = l1_b + E, *l2_b = l2_w + E;
+  free_weights(h);
+  ALLOC(h, h->d_compact, (size_t)n_elems * sizeof(T));
+  HIPCHK(h, hipMemcpy(h->d_compact, w, (size_t)n_elems * sizeof(T), hipMemcpyHostToDevice));
+  // f32 table for the beam kernels
+  if (sizeof(T) == 4) { h->d_emb32 = (float *)h->d_compact; h->emb32_owned = false; }
+  else {
+    ALLOC(h, h->d_emb32, (size_t)num_index * E * 4);
+    h->emb32_owned = true;
+    hipLaunchKernelGGL(dm_f64_to_f32_kernel, dim3(2048), dim3(256), 0, h->stream, (const double *)h->d_compact,
+                       h->d_emb32, num_index * E);
+    HIPCHK(h, hipGetLastError());
+  }
+  // derived small matrices
+  const int NJ = E / 16, NT = E / 16;
+  std::vector<float> wfrag((size_t)NJ * NT * 64 * 4), attT((size_t)E * E), w1bT((size_t)E * E), b1(E), w2(E);
+  for (int jc = 0; jc < NJ; jc++)
+    for (int nt = 0; nt < NT; nt++)
+      for (int ln = 0; ln < 64; ln++)
+        for (int t = 0; t < 4; t++) {
+          int g = ln >> 4, n = ln & 15;
+          wfrag[(((size_t)jc * NT + nt) * 64 + ln) * 4 + t] = (float)l1_w[(size_t)(16 * nt + n) * 2 * E + 16 * jc + 4 * g + t];
+        }
+  for (int o = 0; o < E; o++)
+    for (int k = 0; k < E; k++) {
+      attT[(size_t)k * E + o] = (float)att_w[(size_t)o * E + k];
+      w1bT[(size_t)k * E + o] = (float)l1_w[(size_t)o * 2 * E + E + k];
+    }
+  for (int o = 0; o < E; o++) { b1[o] = (float)l1_b[o]; w2[o] = (float)l2_w[o]; }
+  h->b2 = (float)l2_b[0];
+  ALLOC(h, h->d_wfrag, wfrag.size() * 4);
+  ALLOC(h, h->d_att_wT, attT.size() * 4);
+  ALLOC(h, h->d_w1bT, w1bT.size() * 4);
+  ALLOC(h, h->d_b1, E * 4);
+  ALLOC(h, h->d_w2, E * 4);
+  HIPCHK(h, hipMemcpy(h->d_wfrag, wfrag.data(), wfrag.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_att_wT, attT.data(), attT.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_w1bT, w1bT.data(), w1bT.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_b1, b1.data(), E * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_w2, w2.data(), E * 4, hipMemcpyHostToDevice));
+  // transposes in the loaded dtype for the general forward
+  std::vector<T> attT_t((size_t)E * E), l1T_t((size_t)2 * E * E);
+  for (int o = 0; o < E; o++) {
+    for (int k = 0; k < E; k++) attT_t[(size_t)k * E + o] = att_w[(size_t)o * E + k];
+    for (int k = 0; k < 2 * E; k++) l1T_t[(size_t)k * E + o] = l1_w[(size_t)o * 2 * E + k];
+  }
+  ALLOC(h, h->d_att_wT_t, attT_t.size() * sizeof(T));
+  ALLOC(h, h->d_l1T_t, l1T_t.size() * sizeof(T));
+  HIPCHK(h, hipMemcpy(h->d_att_wT_t, attT_t.data(), attT_t.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_l1T_t, l1T_t.data(), l1T_t.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->embed = E; h->num_index = num_index; h->w_loaded = true;
+  return DM_OK;
+}
+
+int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact, int64_t n_elems) {
+  if (!h) return DM_ERR_INVALID;
+  if (!compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: bad arguments");
+  if (E != 16 && E != 32 && E != 64 && E != 128)
+    return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 16, 32, 64 or 128");
+  if (dtype != DM_F32 && dtype != DM_F64) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: dtype");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->dtype = dtype;
+  return dtype == DM_F32 ? load_weights_t<float>(h, E, num_index, (const float *)compact, n_elems)
+                         : load_weights_t<double>(h, E, num_index, (const double *)compact, n_elems);
+}
+
+template <typename T>
+static int din_forward_t(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
+                         int L, T *d_out) {
+  DinFwdParams<T> p;
+  const T *base = (const T *)h->d_compact;
+  const int E = h->embed;
+  p.emb = base; p.att_wT = (const T *)h->d_att_wT_t; p.l1T = (const T *)h->d_l1T_t;
+  const T *l1_b = base + h->num_index * E + (int64_t)E * E + (int64_t)E * 2 * E;
+  p.b1 = l1_b; p.w2 = l1_b + E;
+  T b2;
+  HIPCHK(h, hipMemcpy(&b2, l1_b + 2 * E, sizeof(T), hipMemcpyDeviceToHost));
+  p.b2 = b2; p.E = E; p.L = L; p.B = B; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.out = d_out;
+  int64_t blocks = (B + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  size_t lds = (size_t)4 * (3 * E + 32) * sizeof(T);
+  hipLaunchKernelGGL(dm_din_forward_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  return DM_OK;
+}
+
+int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
+                   int64_t n_pad, int64_t B, int L, void *logits) {
+  if (!h) return DM_ERR_INVALID;
+  if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_din_forward: weights not loaded");
+  if (!codes || !seqs || !logits || B < 0 || L <= 0 || L > 32 || n_pad < 0 || (n_pad > 0 && !pad_flat_idx))
+    return fail(h, DM_ERR_INVALID, "dm_din_forward: bad arguments (L must be 1..32)");
+  if (B == 0) return DM_OK;
+  // LookupTable.embeddingLookup validates every index first (LookupTable.scala:29-53)
+  for (int64_t i = 0; i < B; i++)
+    if (codes[i] != -1 && (codes[i] < 0 || codes[i] >= h->num_index)) {
+      char b[160]; snprintf(b, sizeof b, "embeddingLookup failed, valid index range is [0, %lld), row %lld got %d", (long long)h->num_index, (long long)i, codes[i]);
+      return fail(h, DM_ERR_INDEX, b);
+    }
+  for (int64_t i = 0; i < B * L; i++)
+    if (seqs[i] != -1 && (seqs[i] < 0 || seqs[i] >= h->num_index)) {
+      char b[160]; snprintf(b, sizeof b, "embeddingLookup failed, valid index range is [0, %lld), row %lld got %d", (long long)h->num_index, (long long)(i / L), seqs[i]);
+      return fail(h, DM_ERR_INDEX, b);
+    }
+  for (int64_t i = 0; i < n_pad; i++)
+    if (pad_flat_idx[i] < 0 || pad_flat_idx[i] >= B * L) return fail(h, DM_ERR_INDEX, "dm_din_forward: mask index outside [0, B*L)");
+  HIPCHK(h, hipSetDevice(h->device));
+  int32_t *d_codes = nullptr, *d_seqs = nullptr, *d_pad = nullptr;
+  unsigned *d_mask = nullptr;
+  void *d_out = nullptr;
+  const size_t esz = h->dtype == DM_F32 ? 4 : 8;
+  ALLOC(h, d_codes, B * 4); ALLOC(h, d_seqs, B * L * 4); ALLOC(h, d_mask, B * 4); ALLOC(h, d_out, B * esz);
+  int rc = DM_OK;
+  do {
+    if (hipMemcpyAsync(d_codes, codes, B * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(d_seqs, seqs, B * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemsetAsync(d_mask, 0, B * 4, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_din_forward: upload failed"); break; }
+    if (n_pad > 0) {
+      if (dm_alloc(h, (void **)&d_pad, n_pad * 4) != DM_OK) { rc = DM_ERR_HIP; break; }
+      if (hipMemcpyAsync(d_pad, pad_flat_idx, n_pad * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+      hipLaunchKernelGGL(dm_pad_rowmask_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, h->stream, d_pad, n_pad, L, d_mask);
+    }
+    rc = h->dtype == DM_F32 ? din_forward_t<float>(h, d_codes, d_seqs, d_mask, B, L, (float *)d_out)
+                            : din_forward_t<double>(h, d_codes, d_seqs, d_mask, B, L, (double *)d_out);
+    if (rc != DM_OK) break;
+    if (hipMemcpyAsync(logits, d_out, B * esz, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("dm_din_forward: ") + hipGetErrorString(hipGetLastError())); break; }
+  } while (0);
+  dm_free_ptr(d_codes); dm_free_ptr(d_seqs); dm_free_ptr(d_mask); dm_free_ptr(d_out); dm_free_ptr(d_pad);
+  return rc;
+}
+
+// ------------------------------------------------------------ beam search
+struct SearchPlan {
+  int nu, cap, grid, ws_cap, lds;
+};
+
+static int plan_search(dm_ctx *h, int max_beam, int64_t U, int n_levels, bool tdm, SearchPlan *pl) {
+  int cap = ((2 * max_beam + 15) / 16) * 16;
+  if (cap < 32) cap = 32;
+  int nu = 0;
+  for (int cand = 8; cand >= 1; cand >>= 1) {
+    BeamLds l = dm_beam_lds(h->embed, cand, cap);
+    if (l.total <= 160 * 1024) { nu = cand; pl->lds = l.total; break; }
+  }
+  if (!nu) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (2*beam*10 bytes + weights must fit 160 KiB)");
+  while (nu > 1 && (int64_t)nu * h->n_cu > U * 2 && nu > 1) nu >>= 1;   // few users: spread over more CUs
+  pl->lds = dm_beam_lds(h->embed, nu, cap).total;
+  int64_t groups = (U + nu - 1) / nu;
+  int grid = (int)(groups < h->n_cu ? groups : h->n_cu);
+  if (grid < 1) grid = 1;
+  pl->nu = nu; pl->cap = cap; pl->grid = grid;
+  pl->ws_cap = tdm ? (h->leaves_at_max_only ? cap : cap * (n_levels + 1)) : 16;
+  return DM_OK;
+}
+
+static int ensure_ws(dm_ctx *h, size_t bytes) {
+  if (h->ws_bytes >= bytes) return DM_OK;
+  dm_free_ptr(h->d_ws); h->d_ws = nullptr; h->ws_bytes = 0;
+  ALLOC(h, h->d_ws, bytes);
+  h->ws_bytes = bytes;
+  return DM_OK;
+}
+
+static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    h->ev_pool.push_back({e0, e1});
+  }
+  *a = h->ev_pool[h->ev_used].first; *b = h->ev_pool[h->ev_used].second;
+  h->ev_used++;
+  return DM_OK;
+}
+
+template <int E>
+static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  hipEvent_t e0, e1;
+  int rc = next_events(h, &e0, &e1);
+  if (rc != DM_OK) return rc;
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  hipLaunchKernelGGL(dm_beam_kernel<E>, dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  return DM_OK;
+}
+
+static int launch_beam(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  switch (h->embed) {
+    case 16: return launch_beam_E<16>(h, p, pl);
+    case 32: return launch_beam_E<32>(h, p, pl);
+    case 64: return launch_beam_E<64>(h, p, pl);
+    case 128: return launch_beam_E<128>(h, p, pl);
+  }
+  return fail(h, DM_ERR_UNSUPPORTED, "unsupported embed size");
+}
+
+static void fill_common(dm_ctx *h, BeamParams &p) {
+  memset(&p, 0, sizeof p);
+  p.emb = h->d_emb32; p.wfrag = h->d_wfrag; p.att_wT = h->d_att_wT; p.w1bT = h->d_w1bT; p.b1 = h->d_b1; p.w2 = h->d_w2;
+  p.b2 = h->b2; p.num_index = h->num_index;
+  p.exists_bits = h->d_exists; p.leaf_bits = h->d_leaf; p.node_id = h->d_node_id; p.id_to_code = h->d_id_to_code;
+  p.n_slots = h->n_slots; p.non_leaf_offset = h->non_leaf_offset; p.max_code = h->max_code; p.max_level = h->max_level;
+  p.scored_rows = h->d_rows;
+}
+
+static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, const dm_tdm_search_opts *o, int max_beam,
+                          const int64_t *d_coff, const int32_t *d_cids, int32_t *d_ids, float *d_scores, int32_t *d_counts,
+                          int trace_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn) {
+  if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "tdm beam search: tree, id maps and weights must be loaded first");
+  if (U <= 0 || L <= 0 || L > DM_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..16)");
+  if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: tree codes exceed the embedding table (embeddingLookup would fail)");
+  if (h->max_code >= h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: id map codes exceed the embedding table");
+  int start, level;
+  level_start_int(o->beam, &start, &level);
+  int n_levels = h->max_level - level + 1;
+  if (n_levels < 0) n_levels = 0;
+  SearchPlan pl;
+  int rc = plan_search(h, max_beam, U, n_levels, true, &pl);
+  if (rc != DM_OK) return rc;
+  const size_t per = (size_t)pl.grid * pl.nu * pl.ws_cap;
+  rc = ensure_ws(h, per * 16);
+  if (rc != DM_OK) return rc;
+  BeamParams p;
+  fill_common(h, p);
+  p.seq = d_seq; p.U = U; p.L = L; p.use_mask = o->use_mask; p.beam = o->beam; p.topk = o->topk;
+  p.widen = (o->widen_consumed && d_coff) ? 1 : 0;
+  p.consumed_off = d_coff; p.consumed_ids = d_cids; p.mode = 0; p.nu = pl.nu; p.cap = pl.cap;
+  p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = o->topk;
+  p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
+  p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
+  p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = trace_levels;
+  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 8, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
+  return launch_beam(h, p, pl);
+}
+
+static int host_max_beam(const dm_tdm_search_opts *o, const int64_t *coff, int64_t U) {
+  int mb = o->beam;
+  if (o->widen_consumed && coff)
+    for (int64_t u = 0; u < U; u++) {
+      int64_t w = ((coff[u + 1] - coff[u]) + o->topk) / 2;   // Recommender.scala:31
+      if (w > mb) mb = (int)w;
+    }
+  return mb;
+}
+
+int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t U, int L, const dm_tdm_search_opts *opts,
+                           const int64_t *d_consumed_off, const int32_t *d_consumed_ids, int32_t *d_out_item_ids,
+                           float *d_out_scores, int32_t *d_out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_seq_item_ids || !opts || !d_out_item_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search_dev: NULL argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  int mb = opts->beam;
+  if (opts->widen_consumed && d_consumed_off) {
+    std::vector<int64_t> coff((size_t)U + 1);
+    HIPCHK(h, hipMemcpy(coff.data(), d_consumed_off, (U + 1) * 8, hipMemcpyDeviceToHost));
+    mb = host_max_beam(opts, coff.data(), U);
+  }
+  return tdm_search_dev(h, d_seq_item_ids, U, L, opts, mb, d_consumed_off, d_consumed_ids, d_out_item_ids, d_out_scores,
+                        d_out_counts, 0, nullptr, nullptr, nullptr);
+}
+
+static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, const dm_tdm_search_opts *opts,
+                           const int64_t *coff, const int32_t *cids, int32_t *out_ids, float *out_scores,
+                           int32_t *out_counts, int max_levels, int32_t *tc, float *ts, int32_t *tn) {
+  if (!seq || !opts || !out_ids || !out_scores || !out_counts || U <= 0 || L <= 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: bad arguments");
+  if (opts->beam <= 0 || opts->topk <= 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: beam and topk must be positive");
+  if ((coff == nullptr) != (cids == nullptr) && coff && coff[U] > 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: consumed_off / consumed_ids must both be given");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int mb = host_max_beam(opts, coff, U);
+  const int cap = ((2 * mb + 15) / 16) * 16 < 32 ? 32 : ((2 * mb + 15) / 16) * 16;
+  int32_t *d_seq = nullptr, *d_cids = nullptr, *d_ids = nullptr, *d_counts = nullptr, *d_tc = nullptr, *d_tn = nullptr;
+  int64_t *d_coff = nullptr;
+  float *d_scores = nullptr, *d_ts = nullptr;
+  int rc = DM_OK;
+  const size_t nout = (size_t)U * opts->topk;
+  do {
+    if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_ids, nout * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_scores, nout * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_counts, (size_t)U * 4)) != DM_OK) break;
+    if (hipMemcpyAsync(d_seq, seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+    if (coff) {
+      const int64_t nc = coff[U];
+      if ((rc = dm_alloc(h, (void **)&d_coff, (size_t)(U + 1) * 8)) != DM_OK) break;
+      if ((rc = dm_alloc(h, (void **)&d_cids, (size_t)(nc > 0 ? nc : 1) * 4)) != DM_OK) break;
+      if (hipMemcpyAsync(d_coff, coff, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+      if (nc > 0 && hipMemcpyAsync(d_cids, cids, (size_t)nc * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+    }
+    if (tn) {
+      const size_t nt = (size_t)U * max_levels;
+      if ((rc = dm_alloc(h, (void **)&d_tc, nt * cap * 4)) != DM_OK) break;
+      if ((rc = dm_alloc(h, (void **)&d_ts, nt * cap * 4)) != DM_OK) break;
+      if ((rc = dm_alloc(h, (void **)&d_tn, nt * 4)) != DM_OK) break;
+      if (hipMemsetAsync(d_tn, 0, nt * 4, h->stream) != hipSuccess || hipMemsetAsync(d_tc, 0, nt * cap * 4, h->stream) != hipSuccess ||
+          hipMemsetAsync(d_ts, 0, nt * cap * 4, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "memset failed"); break; }
+    }
+    rc = tdm_search_dev(h, d_seq, U, L, opts, mb, d_coff, d_cids, d_ids, d_scores, d_counts, tn ? max_levels : 0, d_tc, d_ts, d_tn);
+    if (rc != DM_OK) break;
+    hipError_t e = hipMemcpyAsync(out_ids, d_ids, nout * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, nout * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && tn) {
+      const size_t nt = (size_t)U * max_levels;
+      e = hipMemcpyAsync(tc, d_tc, nt * cap * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, nt * cap * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("tdm beam search: ") + hipGetErrorString(e)); break; }
+    unsigned long long rows = 0;
+    if (hipMemcpy(&rows, h->d_rows, 8, hipMemcpyDeviceToHost) == hipSuccess) h->last_rows = (int64_t)rows;
+  } while (0);
+  dm_free_ptr(d_seq); dm_free_ptr(d_cids); dm_free_ptr(d_ids); dm_free_ptr(d_counts); dm_free_ptr(d_tc); dm_free_ptr(d_tn);
+  dm_free_ptr(d_coff); dm_free_ptr(d_scores); dm_free_ptr(d_ts);
+  return rc;
+}
+
+int dm_tdm_beam_search(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, const dm_tdm_search_opts *opts,
+                       const int64_t *consumed_off, const int32_t *consumed_ids, int32_t *out_item_ids, float *out_scores,
+                       int32_t *out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  return tdm_search_host(h, seq_item_ids, U, L, opts, consumed_off, consumed_ids, out_item_ids, out_scores, out_counts, 0,
+                         nullptr, nullptr, nullptr);
+}
+
+int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, const dm_tdm_search_opts *opts,
+                             int32_t *out_item_ids, float *out_scores, int32_t *out_counts, int max_levels,
+                             int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
+  if (!h) return DM_ERR_INVALID;
+  if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search_trace: bad trace arguments");
+  return tdm_search_host(h, seq_item_ids, U, L, opts, nullptr, nullptr, out_item_ids, out_scores, out_counts, max_levels,
+                         trace_codes, trace_scores, trace_counts);
+}
+
+int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                       int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_otm_beam_search: weights not loaded");
+  if (!seq_codes || !out_node_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
+    return fail(h, DM_ERR_INVALID, "dm_otm_beam_search: bad arguments");
+  if ((((int64_t)1) << (leaf_level + 1)) - 1 > h->num_index) return fail(h, DM_ERR_INDEX, "dm_otm_beam_search: leaf level exceeds the embedding table");
+  for (int64_t i = 0; i < U * L; i++)
+    if (seq_codes[i] != -1 && (seq_codes[i] < 0 || seq_codes[i] >= h->num_index)) return fail(h, DM_ERR_INDEX, "dm_otm_beam_search: history code outside the embedding table");
+  HIPCHK(h, hipSetDevice(h->device));
+  int start, level;
+  level_start_int(beam, &start, &level);
+  SearchPlan pl;
+  int rc = plan_search(h, beam, U, leaf_level - level, false, &pl);
+  if (rc != DM_OK) return rc;
+  const int stride = 2 * beam;
+  int32_t *d_seq = nullptr, *d_ids = nullptr, *d_counts = nullptr;
+  float *d_scores = nullptr;
+  do {
+    if ((rc = ensure_ws(h, (size_t)pl.grid * pl.nu * pl.ws_cap * 16)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_ids, (size_t)U * stride * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_scores, (size_t)U * stride * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_counts, (size_t)U * 4)) != DM_OK) break;
+    hipError_t e = hipMemcpyAsync(d_seq, seq_codes, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ids, 0xFF, (size_t)U * stride * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_scores, 0, (size_t)U * stride * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_rows, 0, 8, h->stream);
+    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: upload failed"); break; }
+    BeamParams p;
+    fill_common(h, p);
+    const size_t per = (size_t)pl.grid * pl.nu * pl.ws_cap;
+    p.seq = d_seq; p.U = U; p.L = L; p.use_mask = 1; p.beam = beam; p.topk = stride; p.mode = 1; p.otm_leaf_level = leaf_level;
+    p.nu = pl.nu; p.cap = pl.cap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
+    p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
+    p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
+    if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
+    e = hipMemcpyAsync(out_node_ids, d_ids, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("dm_otm_beam_search: ") + hipGetErrorString(e)); break; }
+    unsigned long long rows = 0;
+    if (hipMemcpy(&rows, h->d_rows, 8, hipMemcpyDeviceToHost) == hipSuccess) h->last_rows = (int64_t)rows;
+  } while (0);
+  dm_free_ptr(d_seq); dm_free_ptr(d_ids); dm_free_ptr(d_scores); dm_free_ptr(d_counts);
+  return rc;
+}
+
+int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
+                           int32_t *out_item_ids, float *out_scores, int32_t *out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  return fail(h, DM_ERR_UNSUPPORTED, "dm_tdm_bruteforce_topk: not built yet");
+}
+
+// ---- device memory helpers
+int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {
+  if (!h || !dptr) return DM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  return dm_alloc(h, dptr, bytes);
+}
+int dm_dev_free(dm_handle_t h, void *dptr) {
+  if (!h) return DM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (dptr) HIPCHK(h, hipFree(dptr));
+  return DM_OK;
+}
+int dm_memcpy_h2d(dm_handle_t h, void *dst, const void *src, size_t bytes) {
+  if (!h) return DM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return DM_OK;
+}
+int dm_memcpy_d2h(dm_handle_t h, void *dst, const void *src, size_t bytes) {
+  if (!h) return DM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return DM_OK;
+}
+
+// ---- measurement
+int dm_kernel_timing_reset(dm_handle_t h) {
+  if (!h) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ev_used = 0;
+  return DM_OK;
+}
+int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms) {
+  if (!h || !launches || !total_ms) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_used; i++) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+    tot += ms;
+  }
+  *launches = (int)h->ev_used; *total_ms = tot;
+  return DM_OK;
+}
+int dm_last_scored_rows(dm_handle_t h, int64_t *rows) {
+  if (!h || !rows) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned long long r = 0;
+  HIPCHK(h, hipMemcpy(&r, h->d_rows, 8, hipMemcpyDeviceToHost));
+  h->last_rows = (int64_t)r;
+  *rows = h->last_rows;
+  return DM_OK;
+}
+

@@ -1,0 +1,187 @@
+"""Thin object wrapper over the C ABI: one Engine == one dm_handle_t (device + stream)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class DismemberError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dismember_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Engine:
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        rc = N.lib().dm_create(device_id, C.byref(self._h))
+        if rc != 0:
+            raise DismemberError(rc, (N.lib().dm_last_error(None) or b"").decode())
+        self.E = None
+        self.dtype = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().dm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DismemberError(rc, (N.lib().dm_last_error(self._h) or b"").decode())
+
+    # ---- loading
+    def load_tree(self, codes, node_ids, is_leaf, max_level):
+        codes, node_ids = _i32(codes), _i32(node_ids)
+        is_leaf = np.ascontiguousarray(is_leaf, dtype=np.uint8)
+        self.max_level = int(max_level)
+        self._chk(N.lib().dm_load_tree_tdm(self._h, _p(codes, N.i32p), _p(node_ids, N.i32p), _p(is_leaf, N.u8p),
+                                           codes.size, int(max_level)))
+
+    def load_id_maps(self, leaf_item_ids, leaf_codes):
+        a, b = _i32(leaf_item_ids), _i32(leaf_codes)
+        self._chk(N.lib().dm_load_id_maps(self._h, _p(a, N.i32p), _p(b, N.i32p), a.size))
+
+    def load_weights_din(self, compact, E, num_index):
+        w = np.ascontiguousarray(compact)
+        if w.dtype == np.float32:
+            dt = 0
+        elif w.dtype == np.float64:
+            dt = 1
+        else:
+            raise TypeError("weights must be float32 or float64")
+        self._chk(N.lib().dm_load_weights_din(self._h, dt, int(E), int(num_index), w.ctypes.data_as(C.c_void_p), w.size))
+        self.E, self.dtype, self.num_index = int(E), w.dtype, int(num_index)
+
+    # ---- operator level
+    def id_to_code(self, item_ids):
+        ids = _i32(item_ids)
+        codes = np.empty_like(ids)
+        mask = np.empty_like(ids)
+        nm = C.c_int(0)
+        self._chk(N.lib().dm_tdm_id_to_code(self._h, _p(ids, N.i32p), ids.size, _p(codes, N.i32p), _p(mask, N.i32p),
+                                            C.byref(nm)))
+        return codes, mask[:nm.value].copy()
+
+    def din_forward(self, codes, seqs, pad_flat_idx=None, L=None):
+        codes = _i32(codes).ravel()
+        seqs = _i32(seqs)
+        B = codes.size
+        if L is None:
+            L = seqs.shape[-1] if seqs.ndim == 2 else seqs.size // max(B, 1)
+        seqs = seqs.ravel()
+        pad = _i32([] if pad_flat_idx is None else pad_flat_idx).ravel()
+        out = np.empty(B, dtype=self.dtype)
+        self._chk(N.lib().dm_din_forward(self._h, _p(codes, N.i32p), _p(seqs, N.i32p), _p(pad, N.i32p), pad.size, B, L,
+                                         out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- beam search
+    @staticmethod
+    def _csr(consumed, U):
+        if consumed is None:
+            return None, None
+        off = np.zeros(U + 1, np.int64)
+        for u in range(U):
+            off[u + 1] = off[u] + len(consumed[u])
+        ids = _i32(np.concatenate([_i32(c) for c in consumed]) if off[U] > 0 else np.zeros(1, np.int32))
+        return off, ids
+
+    def tdm_beam_search(self, seq_item_ids, beam, topk, use_mask=True, consumed=None, widen_consumed=False):
+        seq = _i32(seq_item_ids)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        opts = N.SearchOpts(int(beam), int(topk), int(bool(use_mask)), int(bool(widen_consumed)))
+        off, cids = self._csr(consumed, U)
+        ids = np.empty((U, topk), np.int32)
+        sc = np.empty((U, topk), np.float32)
+        cnt = np.empty(U, np.int32)
+        self._chk(N.lib().dm_tdm_beam_search(self._h, _p(seq, N.i32p), U, L, C.byref(opts),
+                                             None if off is None else _p(off, N.i64p),
+                                             None if cids is None else _p(cids, N.i32p), _p(ids, N.i32p),
+                                             _p(sc, N.f32p), _p(cnt, N.i32p)))
+        return ids, sc, cnt
+
+    def tdm_beam_search_trace(self, seq_item_ids, beam, topk, use_mask=True, max_levels=None):
+        seq = _i32(seq_item_ids)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        if max_levels is None:
+            max_levels = self.max_level + 2
+        cap = max(32, ((2 * beam + 15) // 16) * 16)
+        opts = N.SearchOpts(int(beam), int(topk), int(bool(use_mask)), 0)
+        ids = np.empty((U, topk), np.int32)
+        sc = np.empty((U, topk), np.float32)
+        cnt = np.empty(U, np.int32)
+        tc = np.zeros((U, max_levels, cap), np.int32)
+        ts = np.zeros((U, max_levels, cap), np.float32)
+        tn = np.zeros((U, max_levels), np.int32)
+        self._chk(N.lib().dm_tdm_beam_search_trace(self._h, _p(seq, N.i32p), U, L, C.byref(opts), _p(ids, N.i32p),
+                                                   _p(sc, N.f32p), _p(cnt, N.i32p), max_levels, _p(tc, N.i32p),
+                                                   _p(ts, N.f32p), _p(tn, N.i32p)))
+        return ids, sc, cnt, tc, ts, tn
+
+    def otm_beam_search(self, seq_codes, beam, leaf_level):
+        seq = _i32(seq_codes)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        ids = np.empty((U, 2 * beam), np.int32)
+        sc = np.empty((U, 2 * beam), np.float32)
+        cnt = np.empty(U, np.int32)
+        self._chk(N.lib().dm_otm_beam_search(self._h, _p(seq, N.i32p), U, L, int(beam), int(leaf_level), _p(ids, N.i32p),
+                                             _p(sc, N.f32p), _p(cnt, N.i32p)))
+        return ids, sc, cnt
+
+    # ---- device-resident path (bench)
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(N.lib().dm_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self._chk(N.lib().dm_dev_free(self._h, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(N.lib().dm_memcpy_h2d(self._h, dptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        self._chk(N.lib().dm_memcpy_d2h(self._h, arr.ctypes.data_as(C.c_void_p), dptr, arr.nbytes))
+
+    def tdm_beam_search_dev(self, d_seq, U, L, beam, topk, d_ids, d_scores, d_counts, use_mask=True):
+        opts = N.SearchOpts(int(beam), int(topk), int(bool(use_mask)), 0)
+        self._chk(N.lib().dm_tdm_beam_search_dev(self._h, d_seq, U, L, C.byref(opts), None, None, d_ids, d_scores,
+                                                 d_counts))
+
+    def synchronize(self):
+        self._chk(N.lib().dm_synchronize(self._h))
+
+    def timing_reset(self):
+        self._chk(N.lib().dm_kernel_timing_reset(self._h))
+
+    def timing_get(self):
+        n, ms = C.c_int(0), C.c_double(0)
+        self._chk(N.lib().dm_kernel_timing_get(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def last_scored_rows(self):
+        r = C.c_int64(0)
+        self._chk(N.lib().dm_last_scored_rows(self._h, C.byref(r)))
+        return r.value

@@ -1,0 +1,78 @@
+"""Mirrors of the reference's L7 facades for the retrieval path.
+
+  TDM  <- tdm/src/main/scala/com/mass/tdm/model/TDM.scala:8-58 (+ Recommender.recommendItems,
+          tdm/.../model/Recommender.scala:18-37)
+  OTM  <- otm/src/main/scala/com/mass/otm/model/OTM.scala:8-61
+
+Same names, argument meaning and result shapes; the level loop and the scorer run in
+libdismember_hip.so.  Sequences may be one user's list (reference signature) or a [U, L]
+batch (what the device is built for).
+"""
+import numpy as np
+
+from .engine import Engine
+
+
+def sigmoid(logit):
+    """TDM.sigmoid: computed in double (TDM.scala:56-58)."""
+    return 1.0 / (1.0 + np.exp(-np.asarray(logit, dtype=np.float64)))
+
+
+class TDM:
+    def __init__(self, engine: Engine, model_name="din"):
+        self.engine = engine
+        self.use_mask = model_name.lower() == "din"   # TDM.apply, TDM.scala:26-29
+
+    def recommend(self, sequence, topk, candidate_num):
+        """TDM.recommend(sequence, topk, candidateNum): Array[(Int, Double)] (TDM.scala:17-22)."""
+        seq = np.asarray(sequence, dtype=np.int32)
+        single = seq.ndim == 1
+        ids, sc, cnt = self.engine.tdm_beam_search(seq, candidate_num, topk, use_mask=self.use_mask)
+        out = [[(int(ids[u, i]), float(sigmoid(sc[u, i]))) for i in range(cnt[u])] for u in range(ids.shape[0])]
+        return out[0] if single else out
+
+    def recommend_items(self, sequence, topk, candidate_num, consumed_items=None):
+        """Recommender.recommendItems (Recommender.scala:18-37): ids only, beam widened by consumed count."""
+        seq = np.asarray(sequence, dtype=np.int32)
+        single = seq.ndim == 1
+        consumed = None
+        if consumed_items is not None:
+            consumed = [consumed_items] if single else consumed_items
+        ids, _, cnt = self.engine.tdm_beam_search(seq, candidate_num, topk, use_mask=self.use_mask, consumed=consumed,
+                                                  widen_consumed=consumed is not None)
+        out = [ids[u, :cnt[u]].copy() for u in range(ids.shape[0])]
+        return out[0] if single else out
+
+
+class OTM:
+    def __init__(self, engine: Engine, item_id_mapping, model_name="din"):
+        """item_id_mapping: dict item -> leaf node id (OTM.scala:8-12)."""
+        self.engine = engine
+        self.item_id_mapping = dict(item_id_mapping)
+        self.id_item_mapping = {v: k for k, v in self.item_id_mapping.items()}
+        n = len(self.item_id_mapping)
+        self.leaf_level = int(np.ceil(np.log(n) / np.log(2)))     # upperLog2, otm/package.scala:16
+        self.use_mask = model_name.lower() == "din"
+        size = (1 << (self.leaf_level + 1)) - 1
+        self._node_to_item = np.full(size, -1, np.int32)
+        for item, node in self.item_id_mapping.items():
+            if 0 <= node < size:
+                self._node_to_item[node] = item
+
+    def recommend(self, sequence, topk, beam_size):
+        """OTM.recommend(sequence, topk, beamSize): Seq[(Int, Double)] (OTM.scala:14-22)."""
+        seq = np.asarray(sequence, dtype=np.int64)
+        single = seq.ndim == 1
+        if single:
+            seq = seq[None, :]
+        codes = np.array([[self.item_id_mapping.get(int(i), -1) for i in row] for row in seq], dtype=np.int32)
+        ids, sc, cnt = self.engine.otm_beam_search(codes, beam_size, self.leaf_level)
+        out = []
+        for u in range(ids.shape[0]):
+            nodes, scores = ids[u, :cnt[u]], sc[u, :cnt[u]]
+            keep = [(int(self._node_to_item[n]), float(s)) for n, s in zip(nodes, scores)
+                    if 0 <= n < self._node_to_item.size and self._node_to_item[n] >= 0]
+            # stable sort descending by score (sortBy(_.score)(Ordering[Double].reverse))
+            order = sorted(range(len(keep)), key=lambda i: -keep[i][1])
+            out.append([(keep[i][0], float(sigmoid(keep[i][1]))) for i in order[:topk]])
+        return out[0] if single else out

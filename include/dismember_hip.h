@@ -1,0 +1,150 @@
+/*
+ * dismember_hip.h — C ABI of libdismember_hip.so, the MI355X (gfx950) native
+ * implementation of dismember's tree beam-search retrieval hot path.
+ *
+ * This is the drop-in boundary: every entry point names the
+ * reference interface it replaces.  The reference has no FFI of its own for
+ * this path (it is pure Scala calling MKL through BigDL's JNI); these are the
+ * functions a JNI shim binds so that the Scala facades
+ *   TDM.recommend            tdm/src/main/scala/com/mass/tdm/model/TDM.scala:17-22
+ *   Recommender.recommendItems  tdm/.../model/Recommender.scala:18-37
+ *   OTM.recommend            otm/src/main/scala/com/mass/otm/model/OTM.scala:14-22
+ *   Module.forward           scalann/.../nn/abstractnn/AbstractModule.scala:19-41
+ * keep their signatures.
+ *
+ * Conventions
+ *   - every function returns 0 (DM_OK) or a negative dm_status; the message of
+ *     the last failure on a handle is dm_last_error(h).  No exception crosses
+ *     the boundary.
+ *   - plain pointers and sizes only.  Host pointers are caller-owned and only
+ *     read/written during the call.  Device memory is owned by the handle.
+ *   - one handle per (device, stream); a handle is thread-compatible (one host
+ *     thread at a time), like one cloned Module in the reference
+ *     (tdm/.../optim/LocalOptimizer.scala:28-44).
+ *   - there is NO CPU fallback: without a usable HIP device dm_create fails.
+ *   - T/ = tdm/src/main/scala/com/mass/tdm/, O/ = otm/src/main/scala/com/mass/otm/,
+ *     S/ = scalann/src/main/scala/com/mass/scalann/ in the citations below.
+ */
+#ifndef DISMEMBER_HIP_H
+#define DISMEMBER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_ctx *dm_handle_t;
+
+typedef enum {
+  DM_OK = 0,
+  DM_ERR_INVALID = -1,     /* bad argument (the reference's `require` failures) */
+  DM_ERR_HIP = -2,         /* HIP runtime error */
+  DM_ERR_STATE = -3,       /* tree / weights not loaded yet */
+  DM_ERR_INDEX = -4,       /* embedding index out of range (LookupTable.scala:47-53 throws) */
+  DM_ERR_UNSUPPORTED = -5  /* shape outside what the kernels are built for */
+} dm_status;
+
+typedef enum { DM_F32 = 0, DM_F64 = 1 } dm_dtype;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int dm_version(void);
+int dm_device_count(int *count);
+int dm_create(int device_id, dm_handle_t *out);
+int dm_destroy(dm_handle_t h);
+const char *dm_last_error(dm_handle_t h); /* h may be NULL: last create-time error */
+int dm_synchronize(dm_handle_t h);        /* hipStreamSynchronize on the handle's stream */
+
+/* ---- index structures (replaces TDMOp.tree, T/operator/TDMOp.scala:18-19,61-82) ---- */
+
+/* codeNodeMap (T/tree/DistTree.scala:40-87): one entry per tree node.
+ * codes[i] = heap code, node_ids[i] = Node.id, is_leaf[i] = Node.is_leaf. */
+int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_ids, const uint8_t *is_leaf,
+                     int64_t n_nodes, int max_level);
+/* idCodeMap + nonLeafOffset + maxCode (DistTree.loadItems, T/tree/DistTree.scala:26-38) */
+int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *leaf_codes, int64_t n);
+/* TDMTree.idToCode (T/tree/TDMTree.scala:35-56); host-side helper, same logic the kernels run on device */
+int dm_tdm_id_to_code(dm_handle_t h, const int32_t *item_ids, int n, int32_t *codes, int32_t *mask_pos,
+                      int *n_mask);
+/* Recommender.getLevelStart (T/model/Recommender.scala:210-216) in integer arithmetic */
+int dm_level_start(int candidate_num, int *start_code, int *level);
+
+/* ---- scorer weights (replaces Serialization.loadModel + DIN.buildModel) ---- */
+
+/* compact parameter vector in Graph.parameters order (S/nn/graphnn/Graph.scala:37-48,
+ * S/nn/mixin/Module.scala:9-45; DIN: T/model/DIN.scala:18-42):
+ *   [emb num_index x E ; att.W E x E ; l1.W E x 2E ; l1.b E ; l2.W 1 x E ; l2.b 1]
+ * E must be a multiple of 16 (16..128). */
+int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact,
+                        int64_t n_elems);
+
+/* ---- operator level: Module.forward(Table(items, seqs, masks)) ---------- */
+
+/* call sites: T/model/Recommender.scala:93-94, O/model/CandidateSearcher.scala:40-50,
+ * O/tree/OTMTree.scala:167-172, jtm/.../optim/TreeLearning.scala:166-168.
+ * codes [B], seqs [B*L] (node codes, -1 = padding), pad_flat_idx [n_pad] = flat
+ * positions i*L+j to mask (S/nn/Mask.scala:27-32).  logits: B values of the
+ * loaded dtype (float or double). */
+int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
+                   int64_t n_pad, int64_t B, int L, void *logits);
+
+/* ---- TDM beam search: Recommender._recommend + TDM.recommend -------------- */
+
+typedef struct {
+  int beam;           /* candidateNum */
+  int topk;
+  int use_mask;       /* 1 for DIN (TDM.apply, T/model/TDM.scala:26-29) */
+  int widen_consumed; /* 1 = recommendItems semantics: beam_u = max((consumed_u+topk)/2, beam)  (:28-33) */
+} dm_tdm_search_opts;
+
+/* seq_item_ids [U*L] raw item ids (0 = padding).  consumed_off [U+1] / consumed_ids: CSR of
+ * already-consumed item ids per user, or NULL/NULL.  Outputs: out_item_ids/out_scores [U*topk]
+ * (scores are LOGITS; the facade applies sigmoid in double like T/model/TDM.scala:56-58),
+ * out_counts [U] (<= topk). */
+int dm_tdm_beam_search(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, const dm_tdm_search_opts *opts,
+                       const int64_t *consumed_off, const int32_t *consumed_ids, int32_t *out_item_ids,
+                       float *out_scores, int32_t *out_counts);
+
+/* Same search, additionally dumping every scored level (parity instrumentation):
+ * trace_codes/trace_scores [U * max_levels * cap], trace_counts [U * max_levels];
+ * cap = 2*beam rounded up to 16; slots past a user's last level have count 0. */
+int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L,
+                             const dm_tdm_search_opts *opts, int32_t *out_item_ids, float *out_scores,
+                             int32_t *out_counts, int max_levels, int32_t *trace_codes, float *trace_scores,
+                             int32_t *trace_counts);
+
+/* ---- OTM beam search: CandidateSearcher.beamSearch (O/model/CandidateSearcher.scala:58-80) ----
+ * seq_codes [U*L] are node ids (OTM.recommend has already mapped items, O/model/OTM.scala:15);
+ * complete tree, no existence filter.  out_node_ids/out_scores [U * 2*beam] = the leaf-level
+ * candidates in order (f32 scorer; the reference runs this path in f64 — tolerance in DESIGN.md). */
+int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                       int32_t *out_node_ids, float *out_scores, int32_t *out_counts);
+
+/* ---- brute force over every leaf (build-defined recall@k oracle) ---- */
+int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
+                           int32_t *out_item_ids, float *out_scores, int32_t *out_counts);
+
+/* ---- device-resident variants (bench: inputs already in HBM when the clock starts) ---- */
+int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr);
+int dm_dev_free(dm_handle_t h, void *dptr);
+int dm_memcpy_h2d(dm_handle_t h, void *dst, const void *src, size_t bytes);
+int dm_memcpy_d2h(dm_handle_t h, void *dst, const void *src, size_t bytes);
+/* asynchronous on the handle's stream; all pointers are device pointers; consumed_* may be NULL */
+int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t U, int L,
+                           const dm_tdm_search_opts *opts, const int64_t *d_consumed_off,
+                           const int32_t *d_consumed_ids, int32_t *d_out_item_ids, float *d_out_scores,
+                           int32_t *d_out_counts);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* HIP events on the handle's stream around every beam-search kernel launched since the last
+ * reset: number of launches and their summed duration. */
+int dm_kernel_timing_reset(dm_handle_t h);
+int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms);
+/* scored rows (node, user) pairs of the last beam-search call, for roofline accounting */
+int dm_last_scored_rows(dm_handle_t h, int64_t *rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISMEMBER_HIP_H */

@@ -1,0 +1,447 @@
+/*
+ * TEST INFRASTRUCTURE — not product code.
+ *
+ * CPU restatement ("oracle") of dismember's TDM / OTM beam-search retrieval
+ * path and its DIN scorer, in plain C.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (dismember_amd/csrc) never does.
+ *
+ * PARITY UNPINNED: the reference (Scala 2.13 + JVM + MKL JNI) can be neither
+ * compiled nor run in the build container and none of its own tests pins a
+ * score, a beam or a tree assignment.  What *is* pinned:
+ *   - SoftMax forward/backward known answers (scalann/src/test/scala/SoftMaxTest.scala:13,23)
+ *   - structural invariants restated in tests/test_oracle.py
+ *   - the reference's bundled trained weights / tree (tests/golden/ .npy and .npz files)
+ *     as golden INPUTS; outputs on them are restatement-derived.
+ *
+ * Citation prefixes:  T/ = tdm/src/main/scala/com/mass/tdm/
+ *                     O/ = otm/src/main/scala/com/mass/otm/
+ *                     S/ = scalann/src/main/scala/com/mass/scalann/
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ DIN */
+#define REAL float
+#define SUFFIX f32
+#define REAL_EXP expf
+#include "din_body.inc"
+#undef REAL
+#undef SUFFIX
+#undef REAL_EXP
+
+#define REAL double
+#define SUFFIX f64
+#define REAL_EXP exp
+#include "din_body.inc"
+#undef REAL
+#undef SUFFIX
+#undef REAL_EXP
+
+/* --------------------------------------------------- Java number orderings */
+
+/* java.lang.Float.compare / compareTo: total order, -0.0 < 0.0, NaN greatest, all NaN equal */
+static int java_float_compare(float x, float y) {
+  if (x < y) return -1;
+  if (x > y) return 1;
+  int32_t a, b;
+  if (x != x) a = 0x7fc00000; else memcpy(&a, &x, 4); /* floatToIntBits canonicalises NaN */
+  if (y != y) b = 0x7fc00000; else memcpy(&b, &y, 4);
+  return a == b ? 0 : (a < b ? -1 : 1);
+}
+static int java_double_compare(double x, double y) {
+  if (x < y) return -1;
+  if (x > y) return 1;
+  int64_t a, b;
+  if (x != x) a = 0x7ff8000000000000LL; else memcpy(&a, &x, 8);
+  if (y != y) b = 0x7ff8000000000000LL; else memcpy(&b, &y, 8);
+  return a == b ? 0 : (a < b ? -1 : 1);
+}
+int orc_java_float_compare(float x, float y) { return java_float_compare(x, y); }
+
+/*
+ * Stable descending argsort (JVM Arrays.sort(Object[]) / sortBy are stable
+ * merges; comparator y.pred.compareTo(x.pred), T/model/Recommender.scala:77-84).
+ * Plain insertion-merge: bottom-up stable merge sort on an index array.
+ */
+static void stable_argsort_desc_f32(const float *v, int32_t *idx, int n) {
+  int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) idx[i] = i;
+  for (int w = 1; w < n; w *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int a = lo, b = mid, o = lo;
+      while (a < mid && b < hi) {
+        /* take from the right run only if it is strictly "smaller" under the descending comparator */
+        if (java_float_compare(v[idx[a]], v[idx[b]]) < 0) tmp[o++] = idx[b++];
+        else tmp[o++] = idx[a++];
+      }
+      while (a < mid) tmp[o++] = idx[a++];
+      while (b < hi) tmp[o++] = idx[b++];
+    }
+    memcpy(idx, tmp, sizeof(int32_t) * n);
+  }
+  free(tmp);
+}
+static void stable_argsort_desc_f64(const double *v, int32_t *idx, int n) {
+  int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) idx[i] = i;
+  for (int w = 1; w < n; w *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int a = lo, b = mid, o = lo;
+      while (a < mid && b < hi) {
+        if (java_double_compare(v[idx[a]], v[idx[b]]) < 0) tmp[o++] = idx[b++];
+        else tmp[o++] = idx[a++];
+      }
+      while (a < mid) tmp[o++] = idx[a++];
+      while (b < hi) tmp[o++] = idx[b++];
+    }
+    memcpy(idx, tmp, sizeof(int32_t) * n);
+  }
+  free(tmp);
+}
+void orc_stable_argsort_desc_f32(const float *v, int32_t *idx, int n) { stable_argsort_desc_f32(v, idx, n); }
+void orc_stable_argsort_desc_f64(const double *v, int32_t *idx, int n) { stable_argsort_desc_f64(v, idx, n); }
+
+/* ------------------------------------------------------------- TDM tree */
+
+/* T/tree/DistTree.scala:26-38 (loadItems) + T/tree/TDMTree.scala:12-33: the
+ * state a loaded TDMTree holds, as dense arrays instead of hash maps. */
+typedef struct {
+  int max_level;
+  int32_t max_code;        /* codes.max over the id-code pairs   (DistTree.scala:36) */
+  int32_t non_leaf_offset; /* leafIds.max + 1                    (DistTree.scala:35) */
+  int64_t n_slots;         /* dense codeNodeMap domain */
+  uint8_t *exists, *is_leaf;
+  int32_t *node_id;
+  int64_t n_ids;           /* dense idCodeMap domain = non_leaf_offset */
+  int32_t *id_to_code;     /* -1 = not a key */
+} orc_tree_t;
+
+void *orc_tree_create(const int32_t *codes, const int32_t *ids, const uint8_t *is_leaf, int64_t n_nodes,
+                      const int32_t *leaf_ids, const int32_t *leaf_codes, int64_t n_leaf, int max_level) {
+  orc_tree_t *t = (orc_tree_t *)calloc(1, sizeof(*t));
+  t->max_level = max_level;
+  int32_t mc = -1;
+  for (int64_t i = 0; i < n_nodes; i++) if (codes[i] > mc) mc = codes[i];
+  for (int64_t i = 0; i < n_leaf; i++) if (leaf_codes[i] > mc) mc = leaf_codes[i];
+  t->n_slots = (int64_t)mc + 1;
+  t->exists = (uint8_t *)calloc(t->n_slots > 0 ? t->n_slots : 1, 1);
+  t->is_leaf = (uint8_t *)calloc(t->n_slots > 0 ? t->n_slots : 1, 1);
+  t->node_id = (int32_t *)calloc(t->n_slots > 0 ? t->n_slots : 1, sizeof(int32_t));
+  for (int64_t i = 0; i < n_nodes; i++) {
+    t->exists[codes[i]] = 1; t->is_leaf[codes[i]] = is_leaf[i] ? 1 : 0; t->node_id[codes[i]] = ids[i];
+  }
+  int32_t mid = -1, mlc = -1;
+  for (int64_t i = 0; i < n_leaf; i++) { if (leaf_ids[i] > mid) mid = leaf_ids[i]; if (leaf_codes[i] > mlc) mlc = leaf_codes[i]; }
+  t->non_leaf_offset = mid + 1;
+  t->max_code = mlc;
+  t->n_ids = t->non_leaf_offset;
+  t->id_to_code = (int32_t *)malloc(sizeof(int32_t) * (t->n_ids > 0 ? t->n_ids : 1));
+  for (int64_t i = 0; i < t->n_ids; i++) t->id_to_code[i] = -1;
+  for (int64_t i = 0; i < n_leaf; i++) if (leaf_ids[i] >= 0) t->id_to_code[leaf_ids[i]] = leaf_codes[i];
+  return t;
+}
+void orc_tree_destroy(void *p) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  if (!t) return;
+  free(t->exists); free(t->is_leaf); free(t->node_id); free(t->id_to_code); free(t);
+}
+int orc_tree_non_leaf_offset(void *p) { return ((orc_tree_t *)p)->non_leaf_offset; }
+int orc_tree_max_code(void *p) { return ((orc_tree_t *)p)->max_code; }
+
+static int tree_contains(const orc_tree_t *t, int64_t code) { return code >= 0 && code < t->n_slots && t->exists[code]; }
+
+/* T/tree/TDMTree.scala:35-56 idToCode: returns the number of mask positions */
+int orc_tdm_id_to_code(void *p, const int32_t *item_ids, int n, int32_t *codes, int32_t *mask_pos) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  int nm = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t id = item_ids[i];
+    if (id == 0) { mask_pos[nm++] = i; codes[i] = -1; }                       /* paddingId -> paddingIdx */
+    else if (id < t->non_leaf_offset && id >= 0 && t->id_to_code[id] >= 0) codes[i] = t->id_to_code[id];
+    else {
+      /* ancestors: wraps like JVM Int subtraction */
+      int32_t tmp = (int32_t)((uint32_t)id - (uint32_t)t->non_leaf_offset);
+      if (tmp > t->max_code) { mask_pos[nm++] = i; codes[i] = -1; }
+      else codes[i] = tmp;
+    }
+  }
+  return nm;
+}
+
+/* T/model/Recommender.scala:210-216 getLevelStart — the reference's own floating formula */
+void orc_level_start(int candidate_num, int *start_code, int *level) {
+  int lv = (int)floor(log((double)candidate_num) / log(2.0));
+  int s = 0;
+  for (int i = 1; i <= lv; i++) s = s * 2 + 1;
+  *start_code = s; *level = lv;
+}
+
+/*
+ * Scorer plug: scores `n` candidate node codes for ONE user whose (already
+ * idToCode'd) history is seq_codes[L] with padding at mask_pos[n_mask].
+ * Mirrors modelInputs.buildInputs + model.forward (Recommender.scala:93-94).
+ */
+typedef int (*orc_scorer_f32)(void *ctx, const int32_t *codes, int n, const int32_t *seq_codes, int L,
+                              const int32_t *mask_pos, int n_mask, float *out);
+
+/* Default scorer = the DIN restatement, fed exactly what duplicateSequence /
+ * MaskModelInputs.buildInputs build (Recommender.scala:138-201): the history
+ * replicated per candidate and the flat mask list m + i*L. */
+int orc_din_scorer_f32(void *din, const int32_t *codes, int n, const int32_t *seq_codes, int L,
+                       const int32_t *mask_pos, int n_mask, float *out) {
+  int32_t *seqs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1) * L);
+  int32_t *pads = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1) * (n_mask > 0 ? n_mask : 1));
+  int64_t np = 0;
+  for (int i = 0; i < n; i++) {
+    memcpy(seqs + (size_t)i * L, seq_codes, sizeof(int32_t) * L);
+    for (int m = 0; m < n_mask; m++) pads[np++] = mask_pos[m] + i * L;
+  }
+  int rc = orc_din_forward_f32(din, codes, seqs, pads, np, n, out);
+  free(seqs); free(pads);
+  return rc;
+}
+
+/*
+ * One iteration of the level fold, integer logic only
+ * (T/model/Recommender.scala:58-101, lines 62-92):
+ *   in : candidates (code, pred) in order
+ *   out: leaves of this level (appended, in candidate order, to leaf_codes/leaf_preds),
+ *        children codes of the pruned beam, in beam order, filtered by existence.
+ * Returns the number of children (0 => the fold's remaining iterations are no-ops).
+ */
+int orc_tdm_level_step(void *p, int beam, const int32_t *cand_codes, const float *cand_preds, int n_cand,
+                       int32_t *leaf_codes, float *leaf_preds, int *n_leaf_out, int32_t *children) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  int32_t *nl_codes = (int32_t *)malloc(sizeof(int32_t) * (n_cand > 0 ? n_cand : 1));
+  float *nl_preds = (float *)malloc(sizeof(float) * (n_cand > 0 ? n_cand : 1));
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (n_cand > 0 ? n_cand : 1));
+  int nl = 0, nleaf = 0;
+  for (int i = 0; i < n_cand; i++) { /* partition(isLeaf), :62-64 */
+    if (t->is_leaf[cand_codes[i]]) { leaf_codes[nleaf] = cand_codes[i]; leaf_preds[nleaf] = cand_preds[i]; nleaf++; }
+    else { nl_codes[nl] = cand_codes[i]; nl_preds[nl] = cand_preds[i]; nl++; }
+  }
+  *n_leaf_out = nleaf;
+  int nb = nl;
+  if (nl > beam) { stable_argsort_desc_f32(nl_preds, order, nl); nb = beam; } /* :74-84 */
+  else for (int i = 0; i < nl; i++) order[i] = i;                           /* :85-87 keeps input order */
+  int nc = 0;
+  for (int i = 0; i < nb; i++) { /* :88-92 */
+    int64_t c = nl_codes[order[i]];
+    if (tree_contains(t, 2 * c + 1)) children[nc++] = (int32_t)(2 * c + 1);
+    if (tree_contains(t, 2 * c + 2)) children[nc++] = (int32_t)(2 * c + 2);
+  }
+  free(nl_codes); free(nl_preds); free(order);
+  return nc;
+}
+
+/*
+ * Final selection: T/model/Recommender.scala:103-106 (drop consumed ids, emit
+ * (id, pred)) followed by T/model/TDM.scala:21 / Recommender.scala:36
+ * (stable sortBy(-pred), take(topk)).  `leaf_*` must already be in the order of
+ * the reference's leafNodes list (latest level first).
+ */
+int orc_tdm_finalize(void *p, const int32_t *leaf_codes, const float *leaf_preds, int n_leaf,
+                     const int32_t *consumed, int n_consumed, int topk, int32_t *out_ids, float *out_preds) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (n_leaf > 0 ? n_leaf : 1));
+  float *pr = (float *)malloc(sizeof(float) * (n_leaf > 0 ? n_leaf : 1));
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (n_leaf > 0 ? n_leaf : 1));
+  int n = 0;
+  for (int i = 0; i < n_leaf; i++) {
+    int32_t id = t->node_id[leaf_codes[i]];
+    int drop = 0;
+    for (int c = 0; c < n_consumed; c++) if (consumed[c] == id) { drop = 1; break; }
+    if (!drop) { ids[n] = id; pr[n] = leaf_preds[i]; n++; }
+  }
+  stable_argsort_desc_f32(pr, order, n);
+  int k = n < topk ? n : topk;
+  for (int i = 0; i < k; i++) { out_ids[i] = ids[order[i]]; out_preds[i] = pr[order[i]]; }
+  free(ids); free(pr); free(order);
+  return k;
+}
+
+/*
+ * Recommender._recommend + TDM.recommend (T/model/Recommender.scala:40-107,
+ * T/model/TDM.scala:17-22).  Output preds are LOGITS (the reference applies
+ * sigmoid in double afterwards, TDM.scala:56-58; callers do that).
+ *
+ * trace (optional): for parity tests. trace_codes/trace_preds receive every
+ * level's scored candidate list back to back, trace_counts[k] its length,
+ * *trace_levels the number of scored levels.
+ * Returns the number of recommendations (<= topk), negative on scorer error.
+ */
+int orc_tdm_recommend(void *p, orc_scorer_f32 scorer, void *ctx, const int32_t *seq_ids, int L, int topk,
+                      int beam, int use_mask, const int32_t *consumed, int n_consumed, int32_t *out_ids,
+                      float *out_preds, int32_t *trace_codes, float *trace_preds, int32_t *trace_counts,
+                      int *trace_levels) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  int32_t *seq_codes = (int32_t *)malloc(sizeof(int32_t) * L);
+  int32_t *mask_pos = (int32_t *)malloc(sizeof(int32_t) * L);
+  int n_mask = orc_tdm_id_to_code(t, seq_ids, L, seq_codes, mask_pos); /* duplicateSequence :171,181 */
+  if (!use_mask) n_mask = 0;                                           /* SeqModelInputs passes no mask */
+  int start, level;
+  orc_level_start(beam, &start, &level);
+  int cap = 2 * beam > 2 * (start + 1) ? 2 * beam : 2 * (start + 1);
+  int n_iter = t->max_level - level + 1; /* (level to tree.maxLevel) */
+  if (n_iter < 0) n_iter = 0;
+  int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * cap);
+  float *pred = (float *)malloc(sizeof(float) * cap);
+  int32_t *child = (int32_t *)malloc(sizeof(int32_t) * cap);
+  /* leafNodes list: level blocks are PREPENDED (leafNodes ++: levelInfo.leafNodes, :66-67) */
+  int64_t leaf_cap = (int64_t)cap * (n_iter + 1);
+  int32_t *lv_codes = (int32_t *)malloc(sizeof(int32_t) * leaf_cap);
+  float *lv_preds = (float *)malloc(sizeof(float) * leaf_cap);
+  int *lv_off = (int *)calloc(n_iter + 2, sizeof(int));
+  int n_cand = 0, n_lv = 0, total_leaf = 0, tl = 0, toff = 0, rc = 0;
+  for (int64_t c = start; c < 2 * (int64_t)start + 1; c++) /* :53-56 */
+    if (tree_contains(t, c)) { cand[n_cand] = (int32_t)c; pred[n_cand] = 0.0f; n_cand++; }
+  for (int it = 0; it < n_iter && n_cand > 0; it++) {
+    int nleaf = 0;
+    int nc = orc_tdm_level_step(t, beam, cand, pred, n_cand, lv_codes + total_leaf, lv_preds + total_leaf, &nleaf, child);
+    lv_off[n_lv] = total_leaf; total_leaf += nleaf; n_lv++; lv_off[n_lv] = total_leaf;
+    if (nc == 0) { n_cand = 0; break; }
+    rc = scorer(ctx, child, nc, seq_codes, L, mask_pos, n_mask, pred);
+    if (rc != 0) break;
+    memcpy(cand, child, sizeof(int32_t) * nc);
+    n_cand = nc;
+    if (trace_counts) {
+      memcpy(trace_codes + toff, cand, sizeof(int32_t) * nc);
+      memcpy(trace_preds + toff, pred, sizeof(float) * nc);
+      trace_counts[tl++] = nc; toff += nc;
+    }
+  }
+  if (trace_levels) *trace_levels = tl;
+  int k = 0;
+  if (rc == 0) {
+    /* NB: candidates still alive after the last iteration are dropped, exactly as the fold does */
+    int32_t *fl_codes = (int32_t *)malloc(sizeof(int32_t) * (total_leaf > 0 ? total_leaf : 1));
+    float *fl_preds = (float *)malloc(sizeof(float) * (total_leaf > 0 ? total_leaf : 1));
+    int o = 0;
+    for (int b = n_lv - 1; b >= 0; b--)
+      for (int i = lv_off[b]; i < lv_off[b + 1]; i++) { fl_codes[o] = lv_codes[i]; fl_preds[o] = lv_preds[i]; o++; }
+    k = orc_tdm_finalize(t, fl_codes, fl_preds, total_leaf, consumed, n_consumed, topk, out_ids, out_preds);
+    free(fl_codes); free(fl_preds);
+  }
+  free(seq_codes); free(mask_pos); free(cand); free(pred); free(child); free(lv_codes); free(lv_preds); free(lv_off);
+  return rc != 0 ? (rc < 0 ? rc : -rc) : k;
+}
+
+/* Recommender.recommendItems (T/model/Recommender.scala:18-37): the eval path
+ * widens the beam for users with many consumed items. */
+int orc_tdm_recommend_items(void *p, orc_scorer_f32 scorer, void *ctx, const int32_t *seq_ids, int L, int topk,
+                            int beam, int use_mask, const int32_t *consumed, int n_consumed, int has_consumed,
+                            int32_t *out_ids, float *out_preds) {
+  int cn = beam;
+  if (has_consumed) { int w = (n_consumed + topk) / 2; cn = w > beam ? w : beam; }
+  else n_consumed = 0;
+  return orc_tdm_recommend(p, scorer, ctx, seq_ids, L, topk, cn, use_mask, consumed, n_consumed, out_ids, out_preds,
+                           NULL, NULL, NULL, NULL);
+}
+
+/* ------------------------------------------------------------------ OTM */
+
+typedef int (*orc_scorer_f64)(void *ctx, const int32_t *codes, int n, const int32_t *seq_codes, int L, double *out);
+
+/* CandidateSearcher.buildInputs (O/model/CandidateSearcher.scala:85-107): history
+ * replicated per candidate; mask = every flat position whose code is paddingIdx. */
+int orc_din_scorer_f64(void *din, const int32_t *codes, int n, const int32_t *seq_codes, int L, double *out) {
+  int32_t *seqs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1) * L);
+  int32_t *pads = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1) * L);
+  int64_t np = 0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < L; j++) {
+      seqs[(size_t)i * L + j] = seq_codes[j];
+      if (seq_codes[j] == -1) pads[np++] = i * L + j;
+    }
+  int rc = orc_din_forward_f64(din, codes, seqs, pads, np, n, out);
+  free(seqs); free(pads);
+  return rc;
+}
+
+/* O/package.scala:15-17 */
+int orc_lower_log2(int n) { return (int)floor(log((double)n) / log(2.0)); }
+int orc_upper_log2(int n) { return (int)ceil(log((double)n) / log(2.0)); }
+
+/* CandidateSearcher.buildBeamNodes (O/model/CandidateSearcher.scala:109-122) */
+int orc_otm_beam_nodes(const int32_t *ids, const double *scores, int n, int beam, int beam_start, int32_t *out) {
+  int o = 0;
+  if (beam_start) {
+    for (int i = 0; i < n; i++) { out[o++] = ids[i] * 2 + 1; out[o++] = ids[i] * 2 + 2; }
+  } else {
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    stable_argsort_desc_f64(scores, order, n);
+    int nb = n < beam ? n : beam;
+    for (int i = 0; i < nb; i++) { out[o++] = ids[order[i]] * 2 + 1; out[o++] = ids[order[i]] * 2 + 2; }
+    free(order);
+  }
+  return o;
+}
+
+/*
+ * CandidateSearcher.beamSearch (O/model/CandidateSearcher.scala:58-80): complete
+ * tree, no existence filter, every level after the first sorts and keeps `beam`.
+ * seq_codes are already node ids (OTM.recommend maps items through itemIdMapping,
+ * O/model/OTM.scala:15).  Returns the number of leaf-level candidates.
+ */
+int orc_otm_beam_search(orc_scorer_f64 scorer, void *ctx, const int32_t *seq_codes, int L, int leaf_level, int beam,
+                        int32_t *out_ids, double *out_scores) {
+  int start_level = orc_lower_log2(beam);
+  int start = 0;
+  for (int i = 1; i <= start_level; i++) start = start * 2 + 1;
+  int n = start + 1; /* Seq.range(startNode, startNode*2+1) */
+  int cap = 2 * (n > beam ? n : beam);
+  int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * cap);
+  double *sc = (double *)malloc(sizeof(double) * cap);
+  int32_t *child = (int32_t *)malloc(sizeof(int32_t) * cap);
+  for (int i = 0; i < n; i++) { ids[i] = start + i; sc[i] = 0.0; }
+  int rc = 0;
+  for (int level = start_level; level < leaf_level; level++) {
+    int nc = orc_otm_beam_nodes(ids, sc, n, beam, level == start_level, child);
+    rc = scorer(ctx, child, nc, seq_codes, L, sc);
+    if (rc != 0) break;
+    memcpy(ids, child, sizeof(int32_t) * nc);
+    n = nc;
+  }
+  if (rc == 0) { memcpy(out_ids, ids, sizeof(int32_t) * n); memcpy(out_scores, sc, sizeof(double) * n); }
+  free(ids); free(sc); free(child);
+  return rc != 0 ? (rc < 0 ? rc : -rc) : n;
+}
+
+/*
+ * OTM.recommend tail (O/model/OTM.scala:17-21): keep candidates that map to an
+ * item, stable sort by score descending, take topk.  node_to_item[node] = item
+ * id or -1.  Scores returned are logits (sigmoid applied by the caller).
+ */
+int orc_otm_finalize(const int32_t *ids, const double *scores, int n, const int32_t *node_to_item, int64_t n_nodes,
+                     int topk, int32_t *out_items, double *out_scores) {
+  int32_t *it = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+  double *sc = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+  int m = 0;
+  for (int i = 0; i < n; i++)
+    if (ids[i] >= 0 && ids[i] < n_nodes && node_to_item[ids[i]] >= 0) { it[m] = node_to_item[ids[i]]; sc[m] = scores[i]; m++; }
+  stable_argsort_desc_f64(sc, order, m);
+  int k = m < topk ? m : topk;
+  for (int i = 0; i < k; i++) { out_items[i] = it[order[i]]; out_scores[i] = sc[order[i]]; }
+  free(it); free(sc); free(order);
+  return k;
+}
+
+/* first n in [1, n_max] where the reference's floating getLevelStart level differs from
+ * floor(log2 n) in integer arithmetic, or 0 when they agree everywhere */
+int orc_level_start_first_mismatch(int n_max) {
+  for (int n = 1; n <= n_max; n++) {
+    int s, lv, il = 0;
+    orc_level_start(n, &s, &lv);
+    while ((2 << il) <= n) il++;
+    if (il != lv || s != (1 << il) - 1) return n;
+    if (orc_lower_log2(n) != il) return n;
+  }
+  return 0;
+}

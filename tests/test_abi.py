@@ -1,0 +1,64 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/dismember_hip.h declares; with no GPU it refuses to run instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dismember_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from dismember_amd import _native
+    _native.build()
+    return _native
+
+
+def test_every_declared_symbol_is_exported(native):
+    lib = C.CDLL(native.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    # the Python binding table covers exactly the declared ABI
+    assert sorted(native.SIGNATURES) == declared
+
+
+def test_no_oracle_or_cpu_fallback_linked(native):
+    out = os.popen("ldd %s" % native.LIB_PATH).read()
+    assert "libamdhip64" in out
+    assert "oracle" not in out
+    blob = open(native.LIB_PATH, "rb").read()
+    assert b"orc_" not in blob
+
+
+def test_fails_loudly_without_gpu(native):
+    lib = native.lib()
+    n = C.c_int(-1)
+    lib.dm_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    rc = lib.dm_create(0, C.byref(h))
+    assert rc != 0 and not h.value
+    assert b"no CPU fallback" in lib.dm_last_error(None)
+    from dismember_amd import DismemberError, Engine
+    with pytest.raises(DismemberError):
+        Engine(0)
+
+
+def test_level_start_integer(native):
+    lib = native.lib()
+    s, l = C.c_int(), C.c_int()
+    for n, exp in ((1, (0, 0)), (2, (1, 1)), (3, (1, 1)), (20, (15, 4)), (200, (127, 7)), (256, (255, 8))):
+        assert lib.dm_level_start(n, C.byref(s), C.byref(l)) == 0
+        assert (s.value, l.value) == exp
+    assert lib.dm_level_start(0, C.byref(s), C.byref(l)) != 0

@@ -1,0 +1,194 @@
+"""CPU tests of the oracle (the restatement of the reference path) — no GPU needed.
+
+What pins the oracle: the reference's SoftMax known answers, its structural
+invariants, an independent numpy statement of the DIN math, and the committed golden outputs
+on the reference's bundled model/tree ("restatement-derived")."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import CANONICAL_TDM_QUERY, numpy_din_forward, random_din_weights, synthetic_tree
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_softmax_known_answer_forward(oracle):
+    # scalann/src/test/scala/SoftMaxTest.scala:8-18 (values from PyTorch, tol 1e-4)
+    x = np.array([[5.0, 2.0, 0.8], [0.3, 0.4, 1.0]])
+    exp = np.array([0.9392, 0.0468, 0.0141, 0.2428, 0.2683, 0.4889]).reshape(2, 3)
+    assert np.abs(oracle.softmax(x) - exp).max() < 1e-4
+    assert np.abs(oracle.softmax(x.astype(np.float32)) - exp).max() < 1e-4
+
+
+def test_softmax_known_answer_backward(oracle):
+    # scalann/src/test/scala/SoftMaxTest.scala:20-28
+    x = np.array([[5.0, 2.0, 0.8], [0.3, 0.4, 1.0]])
+    g = np.array([[0.5, 0.1, 0.6], [0.1, 0.9, 0.6]])
+    exp = np.array([0.0162, -0.0179, 0.0017, -0.1115, 0.0915, 0.0200]).reshape(2, 3)
+    assert np.abs(oracle.softmax_backward(oracle.softmax(x), g) - exp).max() < 1e-4
+
+
+def test_java_float_compare_total_order(oracle):
+    L = oracle.lib()
+    assert L.orc_java_float_compare(-0.0, 0.0) == -1
+    assert L.orc_java_float_compare(0.0, -0.0) == 1
+    assert L.orc_java_float_compare(float("nan"), float("inf")) == 1
+    assert L.orc_java_float_compare(float("nan"), float("nan")) == 0
+    assert L.orc_java_float_compare(1.0, 2.0) == -1
+
+
+def test_stable_argsort_desc_is_stable(oracle):
+    import ctypes as C
+    v = np.array([1.0, 3.0, 3.0, -0.0, 0.0, 3.0, np.nan, 2.0], np.float32)
+    idx = np.empty(v.size, np.int32)
+    oracle.lib().orc_stable_argsort_desc_f32(v.ctypes.data_as(oracle.f32p), idx.ctypes.data_as(oracle.i32p), v.size)
+    assert idx.tolist() == [6, 1, 2, 5, 7, 0, 4, 3]   # NaN first, ties by position, +0.0 before -0.0
+
+
+def test_level_start_float_formula_matches_integer(oracle):
+    # Recommender.getLevelStart uses math.log(n)/math.log(2) (Recommender.scala:210-216)
+    assert oracle.lib().orc_level_start_first_mismatch(1 << 22) == 0
+    assert oracle.level_start(200) == (127, 7)
+    assert oracle.level_start(20) == (15, 4)
+    assert oracle.level_start(1) == (0, 0)
+
+
+def test_fixture_tree_invariants(fixture_tree, oracle_tree):
+    t = fixture_tree
+    # tdm/src/test/scala/TreeInitSpec.scala:44-57 and jtm/src/test/scala/JtmSpec.scala:37-51
+    assert len(t["leaf_ids"]) == len(t["leaf_codes"]) == 3706
+    ml = int(t["max_level"])
+    assert (t["leaf_codes"] >= 2 ** (ml - 1) - 1).all()
+    assert (t["leaf_codes"] >= 2 ** ml - 1).all() and (t["leaf_codes"] <= 2 ** (ml + 1) - 2).all()
+    assert len(set(t["leaf_ids"].tolist())) == 3706           # projection is a bijection
+    assert oracle_tree.non_leaf_offset == int(t["leaf_ids"].max()) + 1
+    assert oracle_tree.max_code == int(t["leaf_codes"].max())
+    leaf_nodes = t["codes"][t["is_leaf"] == 1]
+    assert sorted(leaf_nodes.tolist()) == sorted(t["leaf_codes"].tolist())
+
+
+def test_fixture_weights_layout(fixture_w32, fixture_w64):
+    # otm/src/test/scala/CompactParameterSpec.scala:8-19: one compact, contiguous vector in parameters() order
+    n = 8191 * 16 + 16 * 16 + 16 * 32 + 16 + 16 + 1
+    assert fixture_w32.size == fixture_w64.size == n == 131857
+    assert abs(float(fixture_w32[-1]) + 0.1667024) < 1e-7
+    assert abs(float(fixture_w64[-1]) + 0.22942817) < 1e-8
+
+
+def test_id_to_code(oracle_tree, fixture_tree):
+    codes, mask = oracle_tree.id_to_code(CANONICAL_TDM_QUERY)
+    assert mask.tolist() == [0, 1] and codes[0] == codes[1] == -1
+    lut = dict(zip(fixture_tree["leaf_ids"].tolist(), fixture_tree["leaf_codes"].tolist()))
+    assert codes[2:].tolist() == [lut[i] for i in CANONICAL_TDM_QUERY[2:]]
+    off = oracle_tree.non_leaf_offset
+    codes, mask = oracle_tree.id_to_code([off + 5, off + oracle_tree.max_code, off + oracle_tree.max_code + 1])
+    assert codes.tolist() == [5, oracle_tree.max_code, -1] and mask.tolist() == [2]   # ancestors / out of range
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+def test_din_forward_matches_numpy(oracle, dtype, tol):
+    rng = np.random.default_rng(7)
+    E, L, NI, B = 32, 10, 511, 96
+    w = random_din_weights(rng, E, NI, dtype)
+    codes = rng.integers(0, NI, B).astype(np.int32)
+    seqs = rng.integers(0, NI, (B, L)).astype(np.int32)
+    seqs[rng.random((B, L)) < 0.25] = -1
+    seqs[3] = -1                                            # an all-padding history
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    din = oracle.Din(w, E, L, NI)
+    got = din.forward(codes, seqs, pad)
+    ref = numpy_din_forward(w, E, L, NI, codes, seqs, pad)
+    assert np.abs(got - ref).max() < tol
+    # all-pad row: uniform softmax over zero rows => attention output 0
+    got1 = din.forward(codes[3:4], seqs[3:4], np.arange(L, dtype=np.int32))     # B == 1 path (addmv, bias first)
+    assert abs(got1[0] - ref[3]) < tol
+
+
+def test_din_forward_index_error(oracle_din32):
+    with pytest.raises(IndexError):
+        oracle_din32.forward([8191], [[1] * 10])
+    with pytest.raises(IndexError):
+        oracle_din32.forward([5], [[1] * 9 + [-7]])
+
+
+def test_golden_outputs_pinned(oracle, oracle_tree, oracle_din32, oracle_din64, fixture_otm_mapping):
+    g = json.load(open(os.path.join(GOLDEN, "oracle_outputs.json")))
+    for rec in g["tdm"]:
+        ids, sc = oracle_tree.recommend(oracle_din32, rec["query"], rec["topk"], rec["beam"])
+        assert ids.tolist() == rec["ids"]
+        assert np.array_equal(sc, np.array(rec["logits"], np.float32))
+    rng = np.random.default_rng(g["din_f32"]["seed"])
+    codes = rng.integers(0, 8191, 64).astype(np.int32)
+    seqs = rng.integers(0, 8191, (64, 10)).astype(np.int32)
+    seqs[rng.random((64, 10)) < 0.2] = -1
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    assert np.array_equal(oracle_din32.forward(codes, seqs, pad), np.array(g["din_f32"]["logits"], np.float32))
+    assert np.array_equal(oracle_din64.forward(codes, seqs, pad), np.array(g["din_f64"]["logits"], np.float64))
+    item2node = {int(a): int(b) for a, b in fixture_otm_mapping}
+    for rec in g["otm"]:
+        ids, sc = oracle.otm_beam_search(oracle_din64, [item2node.get(i, -1) for i in rec["query"]], 12, 20)
+        assert ids.tolist() == rec["node_ids"]
+        assert np.array_equal(sc, np.array(rec["scores"]))
+
+
+def test_tdm_recommend_structure(oracle_tree, oracle_din32, fixture_tree):
+    # tdm/src/test/scala/TdmModelTrainSpec.scala:71-96: topk ids, pure function of (weights, tree, sequence)
+    ids, sc = oracle_tree.recommend(oracle_din32, CANONICAL_TDM_QUERY, 3, 20)
+    assert len(ids) == 3 and set(ids.tolist()) <= set(fixture_tree["leaf_ids"].tolist())
+    ids2, sc2 = oracle_tree.recommend(oracle_din32, CANONICAL_TDM_QUERY, 3, 20)
+    assert ids.tolist() == ids2.tolist() and np.array_equal(sc, sc2)
+    assert (np.diff(sc) <= 0).all()
+    # consumed items are dropped before the top-k (Recommender.scala:103-106)
+    ids3, _ = oracle_tree.recommend(oracle_din32, CANONICAL_TDM_QUERY, 3, 20, consumed=[int(ids[0])])
+    assert int(ids[0]) not in ids3.tolist() and ids3.tolist()[:2] == ids.tolist()[1:3]
+
+
+def test_tdm_trace_replay_consistency(oracle_tree, oracle_din32):
+    """level_step + finalize (the integer logic the GPU parity tests replay) reproduce recommend()."""
+    ids, sc, levels = oracle_tree.recommend(oracle_din32, CANONICAL_TDM_QUERY, 10, 20, trace=True)
+    start, lv = 15, 4
+    cand = np.array([c for c in range(start, 2 * start + 1)], np.int32)
+    preds = np.zeros(cand.size, np.float32)
+    leaves = []
+    for codes, scores in levels:
+        lc, lp, ch = oracle_tree.level_step(20, cand, preds)
+        leaves.insert(0, (lc, lp))
+        assert ch.tolist() == codes.tolist()
+        cand, preds = codes, scores
+    lc, lp, ch = oracle_tree.level_step(20, cand, preds)
+    leaves.insert(0, (lc, lp))
+    assert ch.size == 0
+    fl_c = np.concatenate([a for a, _ in leaves]); fl_p = np.concatenate([b for _, b in leaves])
+    fi, fs = oracle_tree.finalize(fl_c, fl_p, 10)
+    assert fi.tolist() == ids.tolist() and np.array_equal(fs, sc)
+
+
+def test_tdm_recommend_on_ragged_synthetic_tree(oracle):
+    rng = np.random.default_rng(3)
+    t = synthetic_tree(rng, 9, 300)          # 300 of 512 leaves: exercises the existence filter
+    tree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    din = oracle.Din(random_din_weights(rng, 16, 1023), 16, 10, 1023)
+    q = rng.choice(t["leaf_ids"], 10)
+    ids, sc = tree.recommend(din, q, 50, 40)
+    assert len(ids) == 50 and len(set(ids.tolist())) == 50
+    ids_all, _ = tree.recommend(din, q, 1000, 1000)      # beam wider than the tree: every item comes back
+    assert sorted(ids_all.tolist()) == sorted(t["leaf_ids"].tolist())
+    # recommendItems widens the beam with the consumed count (Recommender.scala:28-33)
+    consumed = t["leaf_ids"][:100].tolist()
+    r = tree.recommend_items(din, q, 10, 5, consumed=consumed)
+    assert len(r) == 10 and not (set(r.tolist()) & set(consumed))
+
+
+def test_otm_beam_search_structure(oracle, oracle_din64, fixture_otm_mapping):
+    # otm/src/test/scala/OtmModelTrainSpec.scala:47-58 (3 recs) + TreeConstructionSpec.scala:38-48 (leaf range)
+    m = fixture_otm_mapping
+    assert (m[:, 1] >= 2 ** 12 - 1).all() and (m[:, 1] <= 2 ** 13 - 2).all() and len(m) == 3706
+    item2node = {int(a): int(b) for a, b in m}
+    seq = [item2node.get(i, -1) for i in CANONICAL_TDM_QUERY]
+    ids, sc = oracle.otm_beam_search(oracle_din64, seq, 12, 20)
+    assert ids.size == 40 and (ids >= 4095).all() and (ids <= 8190).all()
+    n2i = np.full(8191, -1, np.int32); n2i[m[:, 1]] = m[:, 0]
+    items, scores = oracle.otm_finalize(ids, sc, n2i, 3)
+    assert len(items) == 3 and (np.diff(scores) <= 0).all()
