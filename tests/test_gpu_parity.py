@@ -227,8 +227,10 @@ def test_tdm_round_trip_properties(oracle):
     w = random_din_weights(rng, 128, NI)
     eng = make_engine(t, w, 128)
     seqs = random_histories(rng, t["leaf_ids"], 9, 10)
-    ids, sc, cnt = eng.tdm_beam_search(seqs, 256, 200)
-    ids2, sc2, cnt2 = eng.tdm_beam_search(seqs, 256, 200)
+    # beam 128 -> start level 7 (100 existing nodes <= beam): every level-8 leaf gets scored.
+    # (beam >= 256 would start AT the leaf level and return pred 0.0 for everything, like the reference)
+    ids, sc, cnt = eng.tdm_beam_search(seqs, 128, 200)
+    ids2, sc2, cnt2 = eng.tdm_beam_search(seqs, 128, 200)
     assert np.array_equal(ids, ids2) and np.array_equal(sc, sc2)
     odin = oracle.Din(w, 128, 10, NI)
     otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
@@ -240,6 +242,10 @@ def test_tdm_round_trip_properties(oracle):
         ref = odin.forward(t["leaf_codes"], np.tile(seq_codes, (200, 1)), pad)
         lut = dict(zip(t["leaf_ids"].tolist(), ref.tolist()))
         assert close(sc[u], [lut[int(i)] for i in ids[u]]).all()
+    # degenerate start at the leaf level: unscored candidates keep pred 0.0 (Recommender.scala:53-56)
+    ids0, sc0, cnt0 = eng.tdm_beam_search(seqs[:2], 256, 5)
+    oi, osc = otree.recommend(odin, seqs[0], 5, 256)
+    assert np.array_equal(ids0[0, :cnt0[0]], oi) and (sc0 == 0).all() and (osc == 0).all()
     eng.close()
 
 
