@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — TDM beam-search serving throughput on MI355X (BASELINE.json configs[1]).
+
+Workload: synthetic 1M-item depth-20 binary tree, 128-d embeddings, DIN scorer, beam=200,
+topk=200, L=10 (SURVEY.md §8d "C2").  One step = one beam search over a batch of users whose
+histories are already resident in HBM.  N GPUs = N independent user shards (replicated table,
+no data-path collective; the barrier/max-over-ranks timing uses torch.distributed).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--users", type=int, default=32768, help="users per step per GPU")
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--embed", type=int, default=128)
+    ap.add_argument("--beam", type=int, default=200)
+    ap.add_argument("--topk", type=int, default=200)
+    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--cpu-users", type=int, default=-1, help="oracle sample size (-1 auto, 0 skip)")
+    ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
+    """The CPU oracle (restatement of the reference's Scala path, oracle/) timed on the host cores,
+    one worker thread per core over contiguous user ranges like T/evaluation/Evaluator.scala:28-37."""
+    from oracle import pyoracle as po
+    po.build()
+    otree = po.TdmTree(tree["codes"], tree["ids"], tree["is_leaf"], tree["leaf_ids"], tree["leaf_codes"],
+                       tree["max_level"])
+    din = po.Din(w, E, L, num_index)
+    cores = os.cpu_count() or 1
+    if n_users <= 0:                                   # auto: aim at ~15 s of wall time on all cores
+        t0 = time.perf_counter()
+        otree.recommend(din, seqs[0], topk, beam)
+        otree.recommend(din, seqs[1], topk, beam)
+        per_user = (time.perf_counter() - t0) / 2
+        n_users = int(max(cores, min(8192, 15.0 * cores / max(per_user, 1e-6))))
+    n_users = min(n_users, seqs.shape[0])
+    cores = min(cores, n_users)
+    bounds = np.linspace(0, n_users, cores + 1).astype(int)
+    out = [None] * n_users
+
+    def work(k):
+        for u in range(bounds[k], bounds[k + 1]):
+            out[u] = otree.recommend(din, seqs[u], topk, beam)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    return dict(value=n_users / dt, unit="users/s", cores=cores, kind="port",
+                sample="%d users of the same workload, %.1f s wall, oracle/libdm_oracle.so (scalar C restatement, "
+                       "one thread per core)" % (n_users, dt)), out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from dismember_amd import Engine
+    from dismember_amd import synth
+
+    E, L, depth = a.embed, a.seq_len, a.depth
+    num_index = (1 << (depth + 1)) - 1
+    rng = np.random.default_rng(synth.SEED)
+    tree = synth.make_tree(a.items, depth, rng)
+    w = synth.make_din_weights(E, num_index, rng)
+    urng = np.random.default_rng(synth.SEED + 1 + rank)       # every rank: its own user shard
+    seqs = synth.make_users(tree["leaf_ids"], a.users, L, urng)
+
+    eng = Engine(local)
+    eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth)
+    eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+    eng.load_weights_din(w, E, num_index)
+
+    U = a.users
+    d_seq = eng.dev_alloc(U * L * 4)
+    d_ids = eng.dev_alloc(U * a.topk * 4)
+    d_sc = eng.dev_alloc(U * a.topk * 4)
+    d_cnt = eng.dev_alloc(U * 4)
+    eng.h2d(d_seq, seqs)
+
+    def sync():
+        eng.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+    sync()
+    eng.timing_reset()
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+    sync(); barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_launch, kernel_ms = eng.timing_get()
+    rows = eng.last_scored_rows()                    # scored (node, user) rows of ONE step
+
+    ids = np.empty((U, a.topk), np.int32)
+    sc = np.empty((U, a.topk), np.float32)
+    cnt = np.empty(U, np.int32)
+    eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
+
+    if rank == 0:
+        avg_ms = kernel_ms / max(n_launch, 1)
+        kq = (L + 3) // 4
+        flops_own = 2 * (E * E + 2 * L * E + E)                     # this formulation, per scored row
+        flops_ref = 2 * (2 * L * E + 3 * E * E + E)                 # SURVEY.md §8d, reference formulation
+        mfma_issued = ((E // 16) * 4 + kq * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0
+        ach = rows * flops_own / (avg_ms * 1e-3) / 1e12
+        res = {
+            "metric": "beam-search users/sec (TDM serve, 1M-item depth-20 tree, 128-d, beam 200)",
+            "value": world * U * a.steps / dt,
+            "unit": "users/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
+                                   "beam=%d, topk=%d, L=%d, 1xMI355X per shard (BASELINE.json configs[1])"
+                                   % (a.items, depth, E, a.beam, a.topk, L),
+                       "users_per_step_per_gpu": U, "parallelism": "user-sharded x%d, replicated table" % world,
+                       "scored_rows_per_user": rows / U},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                         "kernel": "dm_beam_kernel<128>", "kernel_ms_avg": avg_ms, "launches": n_launch,
+                         "flops_per_row_algorithmic": flops_own,
+                         "reference_formulation_flops_per_row": flops_ref,
+                         "reference_formulation_tflops": rows * flops_ref / (avg_ms * 1e-3) / 1e12,
+                         "mfma_issued_tflops": rows * mfma_issued / (avg_ms * 1e-3) / 1e12,
+                         "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9},
+        }
+        if world == 1 and a.cpu_users != 0:
+            n_cpu = a.cpu_users
+            base, outs = cpu_baseline(tree, w, E, L, num_index, seqs, a.beam, a.topk, n_cpu)
+            res["cpu_baseline"] = base
+            same = sum(int(np.array_equal(ids[u, :cnt[u]], outs[u][0])) for u in range(len(outs)))
+            res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(outs))
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
