@@ -39,13 +39,15 @@ struct dm_ctx {
   float *d_emb32 = nullptr;    // f32 table (aliases d_compact for DM_F32)
   bool emb32_owned = false;
   f32x4 *d_wfrag = nullptr;
-  float *d_att_wT = nullptr, *d_w1bT = nullptr, *d_b1 = nullptr, *d_w2 = nullptr;
+  f32x4 *d_afrag = nullptr, *d_bfrag = nullptr;
+  float *d_b1 = nullptr, *d_w2 = nullptr;
   float b2 = 0.f;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
   // measurement
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   unsigned long long *d_rows = nullptr;
+  unsigned long long *d_phase = nullptr;   // 8 debug counters
   int64_t last_rows = 0;
   // cached search workspace
   void *d_ws = nullptr;
@@ -221,8 +223,9 @@ int dm_create(int device_id, dm_handle_t *out) {
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipGetDeviceProperties failed"); }
   h->n_cu = prop.multiProcessorCount;
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipStreamCreate failed"); }
-  if (hipMalloc((void **)&h->d_rows, 8) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
-  (void)hipMemset(h->d_rows, 0, 8);
+  if (hipMalloc((void **)&h->d_rows, 16) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
+  (void)hipMemset(h->d_rows, 0, 16);
+  if (hipMalloc((void **)&h->d_phase, 128) == hipSuccess) (void)hipMemset(h->d_phase, 0, 128);
   *out = h;
   return DM_OK;
 }
@@ -233,10 +236,10 @@ static void free_tree(dm_ctx *h) {
 }
 static void free_weights(dm_ctx *h) {
   if (h->emb32_owned) dm_free_ptr(h->d_emb32);
-  dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_att_wT); dm_free_ptr(h->d_w1bT);
+  dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
-  h->d_att_wT = h->d_w1bT = h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
+  h->d_afrag = h->d_bfrag = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
 }
 
 int dm_destroy(dm_handle_t h) {
@@ -244,7 +247,7 @@ int dm_destroy(dm_handle_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h);
-  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_ws);
+  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -284,6 +287,7 @@ int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_id
     ex[c >> 5] |= 1u << (c & 31);
     nid[c] = node_ids[i];
     if (is_leaf[i]) { lf[c >> 5] |= 1u << (c & 31); leaf_codes.push_back((int32_t)c); if (c < first_max) at_max_only = false; }
+    else if (c >= first_max) at_max_only = false;   // a non-leaf on the last level: take the general path
   }
   free_tree(h);
   ALLOC(h, h->d_exists, words * 4);
@@ -360,29 +364,28 @@ static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64
   }
   // derived small matrices
   const int NJ = E / 16, NT = E / 16;
-  std::vector<float> wfrag((size_t)NJ * NT * 64 * 4), attT((size_t)E * E), w1bT((size_t)E * E), b1(E), w2(E);
+  std::vector<float> wfrag((size_t)NJ * NT * 64 * 4), afrag(wfrag.size()), bfrag(wfrag.size()), b1(E), w2(E);
   for (int jc = 0; jc < NJ; jc++)
     for (int nt = 0; nt < NT; nt++)
       for (int ln = 0; ln < 64; ln++)
         for (int t = 0; t < 4; t++) {
           int g = ln >> 4, n = ln & 15;
-          wfrag[(((size_t)jc * NT + nt) * 64 + ln) * 4 + t] = (float)l1_w[(size_t)(16 * nt + n) * 2 * E + 16 * jc + 4 * g + t];
+          const size_t fi = (((size_t)jc * NT + nt) * 64 + ln) * 4 + t;
+          const int k = 16 * jc + 4 * g + t, o = 16 * nt + n;
+          wfrag[fi] = (float)l1_w[(size_t)o * 2 * E + k];        // B[k][o] = W1a[o][k]
+          afrag[fi] = (float)att_w[(size_t)o * E + k];            // B[k][o] = att_w[o][k]
+          bfrag[fi] = (float)l1_w[(size_t)o * 2 * E + E + k];    // B[k][o] = W1b[o][k]
         }
-  for (int o = 0; o < E; o++)
-    for (int k = 0; k < E; k++) {
-      attT[(size_t)k * E + o] = (float)att_w[(size_t)o * E + k];
-      w1bT[(size_t)k * E + o] = (float)l1_w[(size_t)o * 2 * E + E + k];
-    }
   for (int o = 0; o < E; o++) { b1[o] = (float)l1_b[o]; w2[o] = (float)l2_w[o]; }
   h->b2 = (float)l2_b[0];
   ALLOC(h, h->d_wfrag, wfrag.size() * 4);
-  ALLOC(h, h->d_att_wT, attT.size() * 4);
-  ALLOC(h, h->d_w1bT, w1bT.size() * 4);
+  ALLOC(h, h->d_afrag, afrag.size() * 4);
+  ALLOC(h, h->d_bfrag, bfrag.size() * 4);
   ALLOC(h, h->d_b1, E * 4);
   ALLOC(h, h->d_w2, E * 4);
   HIPCHK(h, hipMemcpy(h->d_wfrag, wfrag.data(), wfrag.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_att_wT, attT.data(), attT.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_w1bT, w1bT.data(), w1bT.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_afrag, afrag.data(), afrag.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_bfrag, bfrag.data(), bfrag.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_b1, b1.data(), E * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_w2, w2.data(), E * 4, hipMemcpyHostToDevice));
   // transposes in the loaded dtype for the general forward
@@ -480,24 +483,25 @@ int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, con
 
 // ------------------------------------------------------------ beam search
 struct SearchPlan {
-  int nu, cap, grid, ws_cap, lds;
+  int nteams, cap, pcap, grid, ws_cap, lds;
 };
 
-static int plan_search(dm_ctx *h, int max_beam, int64_t U, int n_levels, bool tdm, SearchPlan *pl) {
+static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, bool tdm, SearchPlan *pl) {
   int cap = ((2 * max_beam + 15) / 16) * 16;
   if (cap < 32) cap = 32;
-  int nu = 0;
-  for (int cand = 8; cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap);
-    if (l.total <= 160 * 1024) { nu = cand; pl->lds = l.total; break; }
+  int pcap = 16;
+  while (pcap < cap) pcap <<= 1;
+  const int kq = (L + 3) / 4;
+  int nteams = 0;
+  for (int cand = 4; cand >= 1; cand >>= 1) {
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq);
+    if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
-  if (!nu) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (2*beam*10 bytes + weights must fit 160 KiB)");
-  while (nu > 1 && (int64_t)nu * h->n_cu > U * 2 && nu > 1) nu >>= 1;   // few users: spread over more CUs
-  pl->lds = dm_beam_lds(h->embed, nu, cap).total;
-  int64_t groups = (U + nu - 1) / nu;
+  if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (about 2*beam*28 bytes + weights must fit 160 KiB)");
+  int64_t groups = (U + nteams - 1) / nteams;
   int grid = (int)(groups < h->n_cu ? groups : h->n_cu);
   if (grid < 1) grid = 1;
-  pl->nu = nu; pl->cap = cap; pl->grid = grid;
+  pl->nteams = nteams; pl->cap = cap; pl->pcap = pcap; pl->grid = grid;
   pl->ws_cap = tdm ? (h->leaves_at_max_only ? cap : cap * (n_levels + 1)) : 16;
   return DM_OK;
 }
@@ -522,17 +526,27 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
   return DM_OK;
 }
 
-template <int E>
-static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
-  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+template <int E, int KQ>
+static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
   hipEvent_t e0, e1;
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  hipLaunchKernelGGL(dm_beam_kernel<E>, dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+  hipLaunchKernelGGL((dm_beam_kernel<E, KQ>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
   return DM_OK;
+}
+
+template <int E>
+static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  switch ((p.L + 3) / 4) {
+    case 1: return launch_beam_EK<E, 1>(h, p, pl);
+    case 2: return launch_beam_EK<E, 2>(h, p, pl);
+    case 3: return launch_beam_EK<E, 3>(h, p, pl);
+    default: return launch_beam_EK<E, 4>(h, p, pl);
+  }
 }
 
 static int launch_beam(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
@@ -547,11 +561,13 @@ static int launch_beam(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
 
 static void fill_common(dm_ctx *h, BeamParams &p) {
   memset(&p, 0, sizeof p);
-  p.emb = h->d_emb32; p.wfrag = h->d_wfrag; p.att_wT = h->d_att_wT; p.w1bT = h->d_w1bT; p.b1 = h->d_b1; p.w2 = h->d_w2;
+  p.emb = h->d_emb32; p.wfrag = h->d_wfrag; p.afrag = h->d_afrag; p.bfrag = h->d_bfrag; p.b1 = h->d_b1; p.w2 = h->d_w2;
   p.b2 = h->b2; p.num_index = h->num_index;
   p.exists_bits = h->d_exists; p.leaf_bits = h->d_leaf; p.node_id = h->d_node_id; p.id_to_code = h->d_id_to_code;
   p.n_slots = h->n_slots; p.non_leaf_offset = h->non_leaf_offset; p.max_code = h->max_code; p.max_level = h->max_level;
   p.scored_rows = h->d_rows;
+  p.phase_cycles = h->d_phase;
+  p.next_user = h->d_rows + 1;
 }
 
 static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, const dm_tdm_search_opts *o, int max_beam,
@@ -566,21 +582,21 @@ static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, con
   int n_levels = h->max_level - level + 1;
   if (n_levels < 0) n_levels = 0;
   SearchPlan pl;
-  int rc = plan_search(h, max_beam, U, n_levels, true, &pl);
+  int rc = plan_search(h, max_beam, U, L, n_levels, true, &pl);
   if (rc != DM_OK) return rc;
-  const size_t per = (size_t)pl.grid * pl.nu * pl.ws_cap;
+  const size_t per = (size_t)pl.grid * pl.nteams * pl.ws_cap;
   rc = ensure_ws(h, per * 16);
   if (rc != DM_OK) return rc;
   BeamParams p;
   fill_common(h, p);
   p.seq = d_seq; p.U = U; p.L = L; p.use_mask = o->use_mask; p.beam = o->beam; p.topk = o->topk;
   p.widen = (o->widen_consumed && d_coff) ? 1 : 0;
-  p.consumed_off = d_coff; p.consumed_ids = d_cids; p.mode = 0; p.nu = pl.nu; p.cap = pl.cap;
+  p.consumed_off = d_coff; p.consumed_ids = d_cids; p.mode = 0; p.nteams = pl.nteams; p.cap = pl.cap; p.pcap = pl.pcap; p.leaf_fast = h->leaves_at_max_only ? 1 : 0;
   p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = o->topk;
   p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
   p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
   p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = trace_levels;
-  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 8, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
   HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
@@ -699,13 +715,13 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
   int start, level;
   level_start_int(beam, &start, &level);
   SearchPlan pl;
-  int rc = plan_search(h, beam, U, leaf_level - level, false, &pl);
+  int rc = plan_search(h, beam, U, L, leaf_level - level, false, &pl);
   if (rc != DM_OK) return rc;
   const int stride = 2 * beam;
   int32_t *d_seq = nullptr, *d_ids = nullptr, *d_counts = nullptr;
   float *d_scores = nullptr;
   do {
-    if ((rc = ensure_ws(h, (size_t)pl.grid * pl.nu * pl.ws_cap * 16)) != DM_OK) break;
+    if ((rc = ensure_ws(h, (size_t)pl.grid * pl.nteams * pl.ws_cap * 16)) != DM_OK) break;
     if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
     if ((rc = dm_alloc(h, (void **)&d_ids, (size_t)U * stride * 4)) != DM_OK) break;
     if ((rc = dm_alloc(h, (void **)&d_scores, (size_t)U * stride * 4)) != DM_OK) break;
@@ -714,13 +730,13 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
     if (e == hipSuccess) e = hipMemsetAsync(d_ids, 0xFF, (size_t)U * stride * 4, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_scores, 0, (size_t)U * stride * 4, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_rows, 0, 8, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_rows, 0, 16, h->stream);
     if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: upload failed"); break; }
     BeamParams p;
     fill_common(h, p);
-    const size_t per = (size_t)pl.grid * pl.nu * pl.ws_cap;
+    const size_t per = (size_t)pl.grid * pl.nteams * pl.ws_cap;
     p.seq = d_seq; p.U = U; p.L = L; p.use_mask = 1; p.beam = beam; p.topk = stride; p.mode = 1; p.otm_leaf_level = leaf_level;
-    p.nu = pl.nu; p.cap = pl.cap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
+    p.nteams = pl.nteams; p.cap = pl.cap; p.pcap = pl.pcap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
     p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
     p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
     if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
@@ -785,6 +801,14 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms) {
     tot += ms;
   }
   *launches = (int)h->ev_used; *total_ms = tot;
+  return DM_OK;
+}
+// debug (not part of the public header): cumulative per-phase wave cycles, DM_PHASE_TIMERS builds
+extern "C" int dm_debug_phase_cycles(dm_handle_t h, unsigned long long *out8) {
+  if (!h || !out8 || !h->d_phase) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out8, h->d_phase, 128, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(h->d_phase, 0, 128));
   return DM_OK;
 }
 int dm_last_scored_rows(dm_handle_t h, int64_t *rows) {
