@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -752,10 +753,88 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
   return rc;
 }
 
+// Brute force over every leaf with the same fused scorer (mode 2 of the beam kernel): the
+// build-defined oracle for recall@k.  Order: score descending, then leaf code ascending.
 int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
                            int32_t *out_item_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
-  return fail(h, DM_ERR_UNSUPPORTED, "dm_tdm_bruteforce_topk: not built yet");
+  if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_bruteforce_topk: tree, id maps and weights must be loaded first");
+  if (!seq_item_ids || !out_item_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || topk <= 0 || topk > 256)
+    return fail(h, DM_ERR_INVALID, "dm_tdm_bruteforce_topk: bad arguments (topk must be 1..256)");
+  if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "dm_tdm_bruteforce_topk: tree codes exceed the embedding table");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int pcap = 512;
+  const int chunk = ((pcap - topk) / 16) * 16;
+  const int cap = chunk < 32 ? 32 : chunk;
+  const int kq = (L + 3) / 4;
+  int nteams = 0, lds = 0;
+  for (int cand = 4; cand >= 1; cand >>= 1) {
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq);
+    if (l.total <= 160 * 1024) { nteams = cand; lds = l.total; break; }
+  }
+  if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "dm_tdm_bruteforce_topk: LDS budget exceeded");
+  // enough (user, slice) work items to fill every team a few times over
+  int64_t slices = (4 * (int64_t)h->n_cu * nteams + U - 1) / U;
+  const int64_t max_slices = (h->n_leaf_nodes + chunk - 1) / chunk;
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  int64_t per = (h->n_leaf_nodes + slices - 1) / slices;
+  per = ((per + 15) / 16) * 16;
+  slices = (h->n_leaf_nodes + per - 1) / per;
+  const int64_t n_work = U * slices;
+  if (n_work >= (1ll << 31)) return fail(h, DM_ERR_UNSUPPORTED, "dm_tdm_bruteforce_topk: too many work items");
+  int32_t *d_seq = nullptr;
+  unsigned long long *d_keys = nullptr;
+  int rc = DM_OK;
+  std::vector<unsigned long long> keys((size_t)n_work * topk);
+  do {
+    if ((rc = ensure_ws(h, 1024)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_keys, keys.size() * 8)) != DM_OK) break;
+    hipError_t e = hipMemcpyAsync(d_seq, seq_item_ids, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_rows, 0, 16, h->stream);
+    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_tdm_bruteforce_topk: upload failed"); break; }
+    BeamParams p;
+    fill_common(h, p);
+    p.seq = d_seq; p.U = U; p.L = L; p.use_mask = use_mask; p.beam = 2; p.topk = topk; p.mode = 2;
+    p.nteams = nteams; p.cap = cap; p.pcap = pcap; p.out_stride = topk;
+    p.bf_leaf_codes = h->d_leaf_codes; p.bf_n_leaf = h->n_leaf_nodes; p.bf_slices = (int)slices; p.bf_chunk = chunk;
+    p.bf_per_slice = per; p.bf_out_keys = d_keys;
+    p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws; p.ws_khi = (uint32_t *)h->d_ws; p.ws_klo = (uint32_t *)h->d_ws;
+    p.ws_cap = 0;
+    SearchPlan pl;
+    pl.nteams = nteams; pl.cap = cap; pl.pcap = pcap; pl.lds = lds; pl.ws_cap = 0;
+    int64_t groups = (n_work + nteams - 1) / nteams;
+    pl.grid = (int)(groups < h->n_cu ? groups : h->n_cu);
+    if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
+    e = hipMemcpyAsync(keys.data(), d_keys, keys.size() * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("dm_tdm_bruteforce_topk: ") + hipGetErrorString(e)); break; }
+    std::vector<int32_t> nid((size_t)h->n_slots);
+    if (hipMemcpy(nid.data(), h->d_node_id, nid.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "node id download failed"); break; }
+    // merge the per-slice winners (keys are unique: descending-score key << 32 | leaf code)
+    std::vector<unsigned long long> row((size_t)slices * topk);
+    for (int64_t u = 0; u < U; u++) {
+      std::copy(keys.begin() + u * slices * topk, keys.begin() + (u + 1) * slices * topk, row.begin());
+      const size_t kk = std::min<size_t>(topk, row.size());
+      std::partial_sort(row.begin(), row.begin() + kk, row.end());
+      int n = 0;
+      for (size_t i = 0; i < kk; i++) {
+        if (row[i] == ~0ull) break;
+        const uint32_t code = (uint32_t)row[i], dk = (uint32_t)(row[i] >> 32);
+        const uint32_t asc = ~dk;
+        const uint32_t bits = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+        float sc; memcpy(&sc, &bits, 4);
+        out_item_ids[u * topk + n] = nid[code];
+        out_scores[u * topk + n] = sc;
+        n++;
+      }
+      for (int i = n; i < topk; i++) { out_item_ids[u * topk + i] = -1; out_scores[u * topk + i] = 0.f; }
+      out_counts[u] = n;
+    }
+  } while (0);
+  dm_free_ptr(d_seq); dm_free_ptr(d_keys);
+  return rc;
 }
 
 // ---- device memory helpers

@@ -149,6 +149,18 @@ class Engine:
                                              _p(sc, N.f32p), _p(cnt, N.i32p)))
         return ids, sc, cnt
 
+    def tdm_bruteforce_topk(self, seq_item_ids, topk, use_mask=True):
+        seq = _i32(seq_item_ids)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        ids = np.empty((U, topk), np.int32)
+        sc = np.empty((U, topk), np.float32)
+        cnt = np.empty(U, np.int32)
+        self._chk(N.lib().dm_tdm_bruteforce_topk(self._h, _p(seq, N.i32p), U, L, int(topk), int(bool(use_mask)),
+                                                 _p(ids, N.i32p), _p(sc, N.f32p), _p(cnt, N.i32p)))
+        return ids, sc, cnt
+
     # ---- device-resident path (bench)
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

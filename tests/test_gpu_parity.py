@@ -282,3 +282,39 @@ def test_otm_beam_search_vs_oracle_f64(fixture_w64, oracle, oracle_din64, fixtur
     ref_items, _ = oracle.otm_finalize(oi, osc, n2i, 3)
     assert [r[0] for r in recs] == ref_items.tolist()
     eng.close()
+
+
+# --------------------------------------------------------------------------- brute force (recall oracle)
+@pytest.mark.parametrize("E,depth,n_items,topk", [(128, 11, 1500, 200), (16, 9, 300, 50), (64, 12, 4000, 256)])
+def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk):
+    """Every leaf scored by the fused kernel == the oracle scorer on every leaf; top-k by (score desc, code asc)."""
+    rng = np.random.default_rng(4242 + E)
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    eng = make_engine(t, w, E)
+    odin = oracle.Din(w, E, 10, NI)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    seqs = random_histories(rng, t["leaf_ids"], 7, 10)
+    seqs[1] = 0
+    ids, sc, cnt = eng.tdm_bruteforce_topk(seqs, topk)
+    k = min(topk, n_items)
+    lut = dict(zip(t["leaf_codes"].tolist(), t["leaf_ids"].tolist()))
+    for u in range(seqs.shape[0]):
+        assert cnt[u] == k
+        seq_codes, mask = otree.id_to_code(seqs[u])
+        pad = (mask[None, :] + (np.arange(n_items) * 10)[:, None]).reshape(-1)
+        ref = odin.forward(t["leaf_codes"], np.tile(seq_codes, (n_items, 1)), pad)
+        gpu_by_id = dict(zip(ids[u, :k].tolist(), sc[u, :k].tolist()))
+        ref_by_id = {lut[int(c)]: float(s) for c, s in zip(t["leaf_codes"], ref)}
+        assert all(close(s, ref_by_id[i]).all() for i, s in gpu_by_id.items())       # scores within tolerance
+        assert (np.diff(sc[u, :k]) <= 0).all()
+        # the returned set is the true top-k up to score tolerance at the cut
+        kth = np.sort(ref)[::-1][k - 1]
+        assert all(ref_by_id[i] >= kth - (ATOL + RTOL * abs(kth)) for i in gpu_by_id)
+    # beam search with a beam wider than the tree == brute force (both sides on the GPU: exact)
+    beam = 1 << (depth - 1)
+    bids, bsc, bcnt = eng.tdm_beam_search(seqs, beam, k)
+    for u in range(seqs.shape[0]):
+        assert np.array_equal(np.sort(bsc[u, :k])[::-1], sc[u, :k])
+    eng.close()
