@@ -49,6 +49,9 @@ SIGNATURES = {
     "dm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dm_tdm_beam_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(SearchOpts),
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dm_fill_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
+    "dm_fill_tree_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64]),
+    "dm_load_weights_din_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
     "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dm_last_scored_rows": (C.c_int, [C.c_void_p, i64p]),

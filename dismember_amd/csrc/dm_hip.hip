@@ -345,25 +345,12 @@ int dm_tdm_id_to_code(dm_handle_t h, const int32_t *item_ids, int n, int32_t *co
   return DM_OK;
 }
 
+// derived, fragment-ordered copies of the small matrices (att.W, l1.W, l1.b, l2.W, l2.b) from the
+// host copy of the tail of the compact vector
 template <typename T>
-static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64_t n_elems) {
-  const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
-  if (need != n_elems) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: n_elems does not match the DIN layout for (E, num_index)");
-  const T *att_w = w + num_index * E, *l1_w = att_w + (int64_t)E * E, *l1_b = l1_w + (int64_t)E * 2 * E;
+static int upload_derived(dm_ctx *h, int E, const T *att_w) {
+  const T *l1_w = att_w + (int64_t)E * E, *l1_b = l1_w + (int64_t)E * 2 * E;
   const T *l2_w = l1_b + E, *l2_b = l2_w + E;
-  free_weights(h);
-  ALLOC(h, h->d_compact, (size_t)n_elems * sizeof(T));
-  HIPCHK(h, hipMemcpy(h->d_compact, w, (size_t)n_elems * sizeof(T), hipMemcpyHostToDevice));
-  // f32 table for the beam kernels
-  if (sizeof(T) == 4) { h->d_emb32 = (float *)h->d_compact; h->emb32_owned = false; }
-  else {
-    ALLOC(h, h->d_emb32, (size_t)num_index * E * 4);
-    h->emb32_owned = true;
-    hipLaunchKernelGGL(dm_f64_to_f32_kernel, dim3(2048), dim3(256), 0, h->stream, (const double *)h->d_compact,
-                       h->d_emb32, num_index * E);
-    HIPCHK(h, hipGetLastError());
-  }
-  // derived small matrices
   const int NJ = E / 16, NT = E / 16;
   std::vector<float> wfrag((size_t)NJ * NT * 64 * 4), afrag(wfrag.size()), bfrag(wfrag.size()), b1(E), w2(E);
   for (int jc = 0; jc < NJ; jc++)
@@ -399,6 +386,27 @@ static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64
   ALLOC(h, h->d_l1T_t, l1T_t.size() * sizeof(T));
   HIPCHK(h, hipMemcpy(h->d_att_wT_t, attT_t.data(), attT_t.size() * sizeof(T), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_l1T_t, l1T_t.data(), l1T_t.size() * sizeof(T), hipMemcpyHostToDevice));
+  return DM_OK;
+}
+
+template <typename T>
+static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64_t n_elems) {
+  const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
+  if (need != n_elems) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: n_elems does not match the DIN layout for (E, num_index)");
+  free_weights(h);
+  ALLOC(h, h->d_compact, (size_t)n_elems * sizeof(T));
+  HIPCHK(h, hipMemcpy(h->d_compact, w, (size_t)n_elems * sizeof(T), hipMemcpyHostToDevice));
+  // f32 table for the beam kernels
+  if (sizeof(T) == 4) { h->d_emb32 = (float *)h->d_compact; h->emb32_owned = false; }
+  else {
+    ALLOC(h, h->d_emb32, (size_t)num_index * E * 4);
+    h->emb32_owned = true;
+    hipLaunchKernelGGL(dm_f64_to_f32_kernel, dim3(2048), dim3(256), 0, h->stream, (const double *)h->d_compact,
+                       h->d_emb32, num_index * E);
+    HIPCHK(h, hipGetLastError());
+  }
+  int rc = upload_derived<T>(h, E, w + num_index * E);
+  if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->embed = E; h->num_index = num_index; h->w_loaded = true;
   return DM_OK;
@@ -414,6 +422,90 @@ int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, cons
   h->dtype = dtype;
   return dtype == DM_F32 ? load_weights_t<float>(h, E, num_index, (const float *)compact, n_elems)
                          : load_weights_t<double>(h, E, num_index, (const double *)compact, n_elems);
+}
+
+int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_compact, int64_t n_elems) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev: bad arguments");
+  if (E != 16 && E != 32 && E != 64 && E != 128) return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din_dev: embed size must be 16, 32, 64 or 128");
+  const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
+  if (need != n_elems) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev: n_elems does not match the DIN layout for (E, num_index)");
+  HIPCHK(h, hipSetDevice(h->device));
+  free_weights(h);
+  h->dtype = DM_F32;
+  h->d_compact = d_compact; h->d_emb32 = d_compact; h->emb32_owned = false;
+  const int64_t tail = n_elems - num_index * E;
+  std::vector<float> t((size_t)tail);
+  HIPCHK(h, hipMemcpy(t.data(), d_compact + num_index * E, (size_t)tail * 4, hipMemcpyDeviceToHost));
+  int rc = upload_derived<float>(h, E, t.data());
+  if (rc != DM_OK) return rc;
+  h->embed = E; h->num_index = num_index; h->w_loaded = true;
+  return DM_OK;
+}
+
+__global__ void dm_fill_normal_kernel(float *out, int64_t n, float mean, float std, unsigned long long seed) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+  for (; i < n; i += stride) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i / 2 + 1);   // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(unsigned)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(unsigned)((z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795864f * u2, &sn, &cs);
+    out[i] = mean + std * r * cs;
+    if (i + 1 < n) out[i + 1] = mean + std * r * sn;
+  }
+}
+
+__global__ void dm_fill_tree_level_kernel(float *emb, int E, int64_t first, int64_t count, float rho, float sd, unsigned long long seed) {
+  // one thread per PAIR of floats of the level's rows; row c = rho * row(parent) + sd * noise
+  const int64_t n2 = count * E / 2;
+  const float cn = sqrtf(1.0f - rho * rho);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = first + (2 * t) / E;
+    const int e = (int)((2 * t) % E);
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(row * (E / 2) + e / 2 + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(unsigned)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(unsigned)((z >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.2831853071795864f * u2, &sn, &cs);
+    float p0 = 0.f, p1 = 0.f, c = 1.0f;
+    if (row > 0) { const int64_t par = (row - 1) >> 1; p0 = emb[par * E + e]; p1 = emb[par * E + e + 1]; c = cn; }
+    emb[row * E + e] = rho * p0 + c * sd * r * cs;
+    emb[row * E + e + 1] = rho * p1 + c * sd * r * sn;
+  }
+}
+
+int dm_fill_tree_normal(dm_handle_t h, float *d_emb, int E, int depth, float rho, float std, uint64_t seed) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_emb || E <= 0 || (E & 1) || depth < 0 || depth > 30 || rho < 0.f || rho >= 1.f) return fail(h, DM_ERR_INVALID, "dm_fill_tree_normal: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int l = 0; l <= depth; l++) {
+    const int64_t first = ((int64_t)1 << l) - 1, count = (int64_t)1 << l;
+    int64_t blocks = (count * E / 2 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dm_fill_tree_level_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, d_emb, E, first, count, rho, std, (unsigned long long)seed);
+    HIPCHK(h, hipGetLastError());
+  }
+  return DM_OK;
+}
+
+int dm_fill_normal(dm_handle_t h, float *d_ptr, int64_t n, float mean, float std, uint64_t seed) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_ptr || n < 0) return fail(h, DM_ERR_INVALID, "dm_fill_normal: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (n == 0) return DM_OK;
+  hipLaunchKernelGGL(dm_fill_normal_kernel, dim3(4096), dim3(256), 0, h->stream, d_ptr, n, mean, std, (unsigned long long)seed);
+  HIPCHK(h, hipGetLastError());
+  return DM_OK;
 }
 
 template <typename T>

@@ -67,6 +67,36 @@ class Engine:
         self._chk(N.lib().dm_load_weights_din(self._h, dt, int(E), int(num_index), w.ctypes.data_as(C.c_void_p), w.size))
         self.E, self.dtype, self.num_index = int(E), w.dtype, int(num_index)
 
+    def load_weights_din_synthetic(self, E, num_index, seed, small=None, tree_depth=None, rho=0.0):
+        """Build the compact DIN vector on the device (N(0, 0.05) table; `small` = host array holding
+        [att.W ; l1.W ; l1.b ; l2.W ; l2.b], defaults to the reference init) and load it without a host copy."""
+        n = num_index * E + 3 * E * E + 2 * E + 1
+        d = self.dev_alloc(n * 4)
+        if tree_depth is not None and rho > 0.0:
+            assert num_index == (1 << (tree_depth + 1)) - 1
+            self._chk(N.lib().dm_fill_tree_normal(self._h, d, int(E), int(tree_depth), float(rho), 0.05, int(seed)))
+        else:
+            self._chk(N.lib().dm_fill_normal(self._h, d, num_index * E, 0.0, 0.05, int(seed)))
+        if small is None:
+            rng = np.random.default_rng(int(seed))
+            small = np.zeros(3 * E * E + 2 * E + 1, np.float32)
+            small[:3 * E * E] = rng.standard_normal(3 * E * E, dtype=np.float32) * 0.05
+            small[3 * E * E + E:3 * E * E + 2 * E] = rng.standard_normal(E, dtype=np.float32) * 0.05
+        small = np.ascontiguousarray(small, dtype=np.float32)
+        assert small.size == 3 * E * E + 2 * E + 1
+        self._chk(N.lib().dm_memcpy_h2d(self._h, C.c_void_p(d.value + num_index * E * 4),
+                                        small.ctypes.data_as(C.c_void_p), small.nbytes))
+        self._chk(N.lib().dm_load_weights_din_dev(self._h, int(E), int(num_index), d, n))
+        self.E, self.dtype, self.num_index = int(E), np.dtype(np.float32), int(num_index)
+        self._synth_ptr, self._synth_n = d, n
+        return d
+
+    def download_weights(self):
+        """Host copy of the compact vector built by load_weights_din_synthetic (for the CPU oracle)."""
+        out = np.empty(self._synth_n, np.float32)
+        self.d2h(out, self._synth_ptr)
+        return out
+
     # ---- operator level
     def id_to_code(self, item_ids):
         ids = _i32(item_ids)

@@ -136,6 +136,18 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
                            const int32_t *d_consumed_ids, int32_t *d_out_item_ids, float *d_out_scores,
                            int32_t *d_out_counts);
 
+/* ---- synthetic-data helpers (bench / tests only; nothing in the reference corresponds) ---- */
+/* fill d_ptr[0..n) (float, device) with N(mean, std): counter-based splitmix64 + Box-Muller, reproducible per (seed, index) */
+int dm_fill_normal(dm_handle_t h, float *d_ptr, int64_t n, float mean, float std, uint64_t seed);
+/* tree-correlated table for a heap of `depth` levels below the root: row(root) ~ N(0, std),
+ * row(c) = rho * row(parent(c)) + sqrt(1 - rho^2) * N(0, std) — a stand-in for a trained index, where
+ * a node's embedding summarises its subtree (with iid rows beam search has nothing to follow and
+ * recall vs brute force is ~0 by construction). */
+int dm_fill_tree_normal(dm_handle_t h, float *d_emb, int E, int depth, float rho, float std, uint64_t seed);
+/* like dm_load_weights_din(DM_F32) but the compact vector already lives in device memory; the handle
+ * takes ownership of d_compact (freed with the handle / on the next load). */
+int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_compact, int64_t n_elems);
+
 /* ---- measurement ----------------------------------------------------------- */
 /* HIP events on the handle's stream around every beam-search kernel launched since the last
  * reset: number of launches and their summed duration. */

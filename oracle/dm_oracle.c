@@ -445,3 +445,51 @@ int orc_level_start_first_mismatch(int n_max) {
   }
   return 0;
 }
+
+/* ------------------------------------------------------------ threaded batch (cpu_baseline) */
+#include <malloc.h>
+#include <pthread.h>
+
+/* One worker per core over contiguous user ranges, as the reference's evaluator splits users over
+ * its thread pool (T/evaluation/Evaluator.scala:28-37).  Each worker runs the plain per-user
+ * orc_tdm_recommend with the DIN restatement as scorer. */
+typedef struct {
+  void *tree, *din;
+  const int32_t *seqs;
+  int64_t u0, u1;
+  int L, topk, beam, use_mask;
+  int32_t *out_ids; float *out_preds; int32_t *out_counts;
+} orc_batch_job;
+
+static void *orc_batch_worker(void *arg) {
+  orc_batch_job *j = (orc_batch_job *)arg;
+  for (int64_t u = j->u0; u < j->u1; u++) {
+    int k = orc_tdm_recommend(j->tree, orc_din_scorer_f32, j->din, j->seqs + u * j->L, j->L, j->topk, j->beam,
+                              j->use_mask, NULL, 0, j->out_ids + u * j->topk, j->out_preds + u * j->topk,
+                              NULL, NULL, NULL, NULL);
+    j->out_counts[u] = k;
+  }
+  return NULL;
+}
+
+int orc_tdm_recommend_batch(void *tree, void *din, const int32_t *seqs, int64_t U, int L, int topk, int beam,
+                            int use_mask, int n_threads, int32_t *out_ids, float *out_preds, int32_t *out_counts) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > U) n_threads = (int)U;
+  /* the per-call scratch buffers must come from per-thread arenas, not mmap/munmap (which serialise
+   * every thread on the process address-space lock and dominate beyond ~32 threads) */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_ARENA_MAX, n_threads + 8);
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+  orc_batch_job *jobs = (orc_batch_job *)malloc(sizeof(orc_batch_job) * n_threads);
+  for (int t = 0; t < n_threads; t++) {
+    orc_batch_job j = {tree, din, seqs, U * t / n_threads, U * (t + 1) / n_threads, L, topk, beam, use_mask,
+                       out_ids, out_preds, out_counts};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, orc_batch_worker, &jobs[t]);
+  }
+  for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  free(th); free(jobs);
+  return 0;
+}

@@ -67,6 +67,8 @@ def lib():
                                         C.POINTER(C.c_int)]
         L.orc_tdm_recommend_items.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, i32p, C.c_int, C.c_int,
                                               C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p, f32p]
+        L.orc_tdm_recommend_batch.argtypes = [C.c_void_p, C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, i32p, f32p, i32p]
         L.orc_lower_log2.argtypes = [C.c_int]
         L.orc_upper_log2.argtypes = [C.c_int]
         L.orc_otm_beam_nodes.argtypes = [i32p, f64p, C.c_int, C.c_int, C.c_int, i32p]
@@ -209,6 +211,17 @@ class TdmTree:
                 off += n
             return oi[:k].copy(), op[:k].copy(), levels
         return oi[:k].copy(), op[:k].copy()
+
+    def recommend_batch(self, din, seqs, topk, beam, use_mask=True, n_threads=1):
+        """TDM.recommend for a [U, L] batch on n_threads worker threads (contiguous user ranges)."""
+        seqs = _i32(seqs)
+        U, L = seqs.shape
+        oi = np.full((U, topk), -1, np.int32)
+        op = np.zeros((U, topk), np.float32)
+        oc = np.zeros(U, np.int32)
+        lib().orc_tdm_recommend_batch(self.h, din.h, _p(seqs, i32p), U, L, topk, beam, int(use_mask), int(n_threads),
+                                      _p(oi, i32p), _p(op, f32p), _p(oc, i32p))
+        return oi, op, oc
 
     def recommend_items(self, din, seq_ids, topk, beam, use_mask=True, consumed=None):
         seq = _i32(seq_ids)
