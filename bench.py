@@ -88,16 +88,11 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    from dismember_amd import sharding
+    dist, rank, world, local = sharding.init_distributed()
     torch = None
-    if world > 1:
+    if dist is not None:
         import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from dismember_amd import Engine
     from dismember_amd import synth
 
@@ -108,7 +103,7 @@ def main():
     urng = np.random.default_rng(synth.SEED + 1 + rank)       # every rank: its own user shard
     seqs = synth.make_users(tree["leaf_ids"], a.users, L, urng)
 
-    eng = Engine(local)
+    eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))   # override only for single-GPU smoke tests of the N>1 path
     eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth)
     eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
     # table generated on the device (same bits on every rank); tree-correlated rows so that the beam has
@@ -141,10 +136,7 @@ def main():
         eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync(); barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, dist)
     n_launch, kernel_ms = eng.timing_get()
     rows = eng.last_scored_rows()                    # scored (node, user) rows of ONE step
 
