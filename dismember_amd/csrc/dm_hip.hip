@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "beam_kernel.hip.inc"
+#include "rows_kernel.hip.inc"
 
 #define DM_VERSION 100
 
@@ -41,6 +42,7 @@ struct dm_ctx {
   bool emb32_owned = false;
   f32x4 *d_wfrag = nullptr;
   f32x4 *d_afrag = nullptr, *d_bfrag = nullptr;
+  f32x4 *d_attA = nullptr, *d_w1aA = nullptr, *d_w1bA = nullptr;   // A-fragment order (rows kernel)
   float *d_b1 = nullptr, *d_w2 = nullptr;
   float b2 = 0.f;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
@@ -237,10 +239,10 @@ static void free_tree(dm_ctx *h) {
 }
 static void free_weights(dm_ctx *h) {
   if (h->emb32_owned) dm_free_ptr(h->d_emb32);
-  dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag);
+  dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
-  h->d_afrag = h->d_bfrag = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
+  h->d_afrag = h->d_bfrag = nullptr; h->d_attA = h->d_w1aA = h->d_w1bA = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
 }
 
 int dm_destroy(dm_handle_t h) {
@@ -366,6 +368,25 @@ static int upload_derived(dm_ctx *h, int E, const T *att_w) {
         }
   for (int o = 0; o < E; o++) { b1[o] = (float)l1_b[o]; w2[o] = (float)l2_w[o]; }
   h->b2 = (float)l2_b[0];
+  // A-fragment order for the transposed products of the rows kernel: [mt][jc][lane] float4,
+  // element t = W[16mt + (lane&15)][16jc + 4(lane>>4) + t]
+  std::vector<float> attA(wfrag.size()), w1aA(wfrag.size()), w1bA(wfrag.size());
+  for (int mt = 0; mt < NT; mt++)
+    for (int jc = 0; jc < NJ; jc++)
+      for (int ln = 0; ln < 64; ln++)
+        for (int t = 0; t < 4; t++) {
+          const size_t fi = (((size_t)mt * NJ + jc) * 64 + ln) * 4 + t;
+          const int o = 16 * mt + (ln & 15), k = 16 * jc + 4 * (ln >> 4) + t;
+          attA[fi] = (float)att_w[(size_t)o * E + k];
+          w1aA[fi] = (float)l1_w[(size_t)o * 2 * E + k];
+          w1bA[fi] = (float)l1_w[(size_t)o * 2 * E + E + k];
+        }
+  ALLOC(h, h->d_attA, attA.size() * 4);
+  ALLOC(h, h->d_w1aA, w1aA.size() * 4);
+  ALLOC(h, h->d_w1bA, w1bA.size() * 4);
+  HIPCHK(h, hipMemcpy(h->d_attA, attA.data(), attA.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_w1aA, w1aA.data(), w1aA.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_w1bA, w1bA.data(), w1bA.size() * 4, hipMemcpyHostToDevice));
   ALLOC(h, h->d_wfrag, wfrag.size() * 4);
   ALLOC(h, h->d_afrag, afrag.size() * 4);
   ALLOC(h, h->d_bfrag, bfrag.size() * 4);
@@ -528,6 +549,35 @@ static int din_forward_t(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seq
   return DM_OK;
 }
 
+template <int E>
+static int launch_rows_E(dm_ctx *h, const RowsParams &p) {
+  const int lds = 2 * E * E * 4;
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_din_rows_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int64_t tiles = (p.B + 15) / 16;
+  int64_t blocks = (tiles + DM_NWAVES - 1) / DM_NWAVES;
+  if (blocks > h->n_cu) blocks = h->n_cu;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dm_din_rows_kernel<E>, dim3((unsigned)blocks), dim3(DM_BLOCK), lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  return DM_OK;
+}
+
+// f32 general-rows forward on device buffers (asynchronous on the handle's stream)
+static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
+                        int L, float *d_out) {
+  RowsParams p;
+  p.emb = h->d_emb32; p.attA = h->d_attA; p.w1aA = h->d_w1aA; p.w1bA = h->d_w1bA; p.b1 = h->d_b1; p.w2 = h->d_w2;
+  p.b2 = h->b2; p.num_index = h->num_index; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.B = B; p.L = L;
+  p.out = d_out;
+  switch (h->embed) {
+    case 16: return launch_rows_E<16>(h, p);
+    case 32: return launch_rows_E<32>(h, p);
+    case 64: return launch_rows_E<64>(h, p);
+    case 128: return launch_rows_E<128>(h, p);
+  }
+  return fail(h, DM_ERR_UNSUPPORTED, "unsupported embed size");
+}
+
 int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
                    int64_t n_pad, int64_t B, int L, void *logits) {
   if (!h) return DM_ERR_INVALID;
@@ -564,7 +614,8 @@ int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, con
       if (hipMemcpyAsync(d_pad, pad_flat_idx, n_pad * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
       hipLaunchKernelGGL(dm_pad_rowmask_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, h->stream, d_pad, n_pad, L, d_mask);
     }
-    rc = h->dtype == DM_F32 ? din_forward_t<float>(h, d_codes, d_seqs, d_mask, B, L, (float *)d_out)
+    rc = h->dtype == DM_F32 ? (L <= DM_MAXL ? din_rows_dev(h, d_codes, d_seqs, d_mask, B, L, (float *)d_out)
+                                            : din_forward_t<float>(h, d_codes, d_seqs, d_mask, B, L, (float *)d_out))
                             : din_forward_t<double>(h, d_codes, d_seqs, d_mask, B, L, (double *)d_out);
     if (rc != DM_OK) break;
     if (hipMemcpyAsync(logits, d_out, B * esz, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
