@@ -43,6 +43,9 @@ SIGNATURES = {
                                            i32p, C.c_int, i32p, f32p, i32p]),
     "dm_otm_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
     "dm_tdm_bruteforce_topk": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
+    "dm_jtm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, f32p]),
+    "dm_jtm_rebalance": (C.c_int, [C.c_void_p, f32p, i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]),
     "dm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

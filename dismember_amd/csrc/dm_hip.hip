@@ -980,6 +980,8 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
   return rc;
 }
 
+#include "jtm_host.hip.inc"
+
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {
   if (!h || !dptr) return DM_ERR_INVALID;

@@ -1,0 +1,84 @@
+"""JTM tree learning: mirror of com.mass.jtm.optim.JTM (jtm/src/main/scala/com/mass/jtm/optim/JTM.scala:8-73).
+
+`JTM(...).optimize()` returns the new projection item id -> leaf code, like the reference's
+`Map[Int, Int]`.  Scoring (TreeLearning.aggregateWeights) runs on the GPU through dm_jtm_child_weights;
+the greedy re-balance is the exact host logic of dm_jtm_rebalance.  Items are iterated in ascending id
+(the reference iterates a Scala HashMap — only relevant for ties).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .engine import Engine, _i32, _p
+
+
+class JTM:
+    def __init__(self, engine: Engine, leaf_item_ids, leaf_codes, max_level, item_rows, gap=2, seq_len=10,
+                 hierarchical=False, min_level=0, use_mask=True):
+        """item_rows: dict item id -> int array [n_rows * seq_len] (itemSequenceMap, TreeLearning.scala:34-46)."""
+        self.engine = engine
+        self.items = np.sort(_i32(leaf_item_ids))
+        lut = dict(zip(_i32(leaf_item_ids).tolist(), _i32(leaf_codes).tolist()))
+        self.item_code = np.array([lut[int(i)] for i in self.items], np.int32)      # code in the CURRENT tree
+        self.max_level, self.gap, self.L = int(max_level), int(gap), int(seq_len)
+        self.hierarchical, self.min_level, self.use_mask = bool(hierarchical), int(min_level), bool(use_mask)
+        off = np.zeros(self.items.size + 1, np.int64)
+        rows = []
+        for k, it in enumerate(self.items.tolist()):
+            r = _i32(item_rows.get(it, np.zeros(0, np.int32))).ravel()
+            assert r.size % self.L == 0
+            off[k + 1] = off[k] + r.size // self.L
+            rows.append(r)
+        self.row_off = off
+        self.row_ids = _i32(np.concatenate(rows)) if off[-1] > 0 else np.zeros(self.L, np.int32)
+
+    def child_weights(self, item_node, old_level, level):
+        n = self.items.size
+        nchild = 1 << (level - old_level)
+        w = np.empty((n, nchild), np.float32)
+        node = _i32(item_node)
+        self.engine._chk(N.lib().dm_jtm_child_weights(self.engine._h, _p(self.row_off, N.i64p), _p(self.row_ids, N.i32p),
+                                                      _p(node, N.i32p), n, self.L, old_level, level,
+                                                      int(self.hierarchical), self.min_level, int(self.use_mask),
+                                                      _p(w, N.f32p)))
+        return w
+
+    def rebalance(self, weights, old_node, node, old_level, level, max_assign):
+        weights = np.ascontiguousarray(weights, np.float32)
+        old_node = _i32(old_node)
+        out = np.empty(old_node.size, np.int32)
+        self.engine._chk(N.lib().dm_jtm_rebalance(self.engine._h, _p(weights, N.f32p), _p(old_node, N.i32p), old_node.size,
+                                                  int(node), old_level, level, int(max_assign), _p(out, N.i32p)))
+        return out
+
+    @staticmethod
+    def ancestor_at_level(codes, level):
+        """JTMTree.getAncestorAtLevel (JTMTree.scala:36-43), vectorised over codes."""
+        c = np.asarray(codes, np.int64).copy()
+        lim = (1 << (level + 1)) - 1
+        while True:
+            m = c >= lim
+            if not m.any():
+                return c.astype(np.int32)
+            c[m] = (c[m] - 1) >> 1
+
+    def optimize(self, weight_fn=None):
+        """JTM.optimize (JTM.scala:22-73).  weight_fn(item_node, old_level, level) -> [n, 2^gap] overrides the GPU
+        scorer (parity tests feed the oracle's weights through the same assignment logic)."""
+        proj = np.zeros(self.items.size, np.int32)            # first all assigned to the root (:23-26)
+        for old_level in range(0, self.max_level, self.gap):
+            level = min(self.max_level, old_level + self.gap)
+            w = (weight_fn or self.child_weights)(proj, old_level, level)
+            old_node = self.ancestor_at_level(self.item_code, level)
+            max_assign = 1 << (self.max_level - level)         # TreeLearning.scala:56
+            new = proj.copy()
+            order = np.argsort(proj, kind="stable")            # items of one node, ascending item id
+            bounds = np.flatnonzero(np.diff(proj[order])) + 1
+            for grp in np.split(order, bounds):
+                node = int(proj[grp[0]])
+                out = self.rebalance(w[grp], old_node[grp], node, old_level, level, max_assign)
+                keep = out >= 0
+                new[grp[keep]] = out[keep]                      # dropped items keep their old node (foldLeft(_ ++ _), :72)
+            proj = new
+        return dict(zip(self.items.tolist(), proj.tolist()))

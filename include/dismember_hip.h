@@ -125,6 +125,24 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
 int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
                            int32_t *out_item_ids, float *out_scores, int32_t *out_counts);
 
+/* ---- JTM / OTM tree learning (jtm/src/main/scala/com/mass/jtm/optim/TreeLearning.scala) ---------------
+ * One gap step of JTM.optimize (jtm/.../optim/JTM.scala:29-70) for n_items items:
+ *   row_off [n_items+1] / row_item_ids [rows*L]: the item's training rows = itemSequenceMap (:34-46), raw item
+ *   ids, L per row; item_node [n_items]: node code (at old_level) each item currently sits in.
+ * weights [n_items * 2^(level-old_level)] = aggregateWeights (:152-174) per child, children ordered as
+ * JTMTree.getChildrenAtLevel (jtm/.../tree/JTMTree.scala:53-57); items without rows get -1e6 (:160).
+ * The DIN forwards run on the GPU; Tensor.sum and the chain accumulation keep the reference's fp32 order. */
+int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, const int32_t *item_node,
+                         int64_t n_items, int L, int old_level, int level, int hierarchical, int min_level, int use_mask,
+                         float *weights);
+/* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable
+ * descending), first choice, greedy capacity-bounded reBalance (:217-265).  old_node [n] =
+ * tree.getAncestorAtLevel(item, level); out_node [n] = assigned child code (-1: dropped by the greedy loop).
+ * Host-side exact integer logic (parents are independent; callers may run it from several threads on
+ * different handles). */
+int dm_jtm_rebalance(dm_handle_t h, const float *weights, const int32_t *old_node, int64_t n, int32_t node, int old_level,
+                     int level, int max_assign, int32_t *out_node);
+
 /* ---- device-resident variants (bench: inputs already in HBM when the clock starts) ---- */
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr);
 int dm_dev_free(dm_handle_t h, void *dptr);

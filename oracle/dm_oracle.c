@@ -493,3 +493,167 @@ int orc_tdm_recommend_batch(void *tree, void *din, const int32_t *seqs, int64_t 
   free(th); free(jobs);
   return 0;
 }
+
+/* ------------------------------------------------------------------ JTM tree learning
+ * J/ = jtm/src/main/scala/com/mass/jtm/
+ * Restates J/optim/JTM.scala:22-73 (optimize), J/optim/TreeLearning.scala:48-194 (child weights) and
+ * :217-265 (reBalance), J/tree/JTMTree.scala:36-113 (ancestor / idToCode).
+ *
+ * UNPINNED detail: JTM.optimize groups items through Scala immutable HashMaps
+ * (`oldProjection.toArray.groupMap`, JTM.scala:31), so the order of `itemsAssignedToNode` — which only
+ * breaks ties between items with EQUAL (moved?, weight) keys in reBalance — is the JVM's hash-trie
+ * iteration order.  This restatement uses ascending item id (the order items are passed in).
+ */
+
+/* JTMTree.getAncestorAtLevel (J/tree/JTMTree.scala:36-43) on a node code */
+static int32_t jtm_ancestor_code(int32_t code, int level) {
+  const int64_t lim = ((int64_t)1 << (level + 1)) - 1;
+  while (code >= lim) code = (code - 1) >> 1;
+  return code;
+}
+int32_t orc_jtm_ancestor_at_level(void *p, int32_t item, int level) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  return jtm_ancestor_code(t->id_to_code[item], level);
+}
+
+/* JTMTree.idToCodeWithMask (J/tree/JTMTree.scala:86-113): mask holds ONLY padding-id positions */
+int orc_jtm_id_to_code_with_mask(void *p, const int32_t *ids, int n, int level, int hierarchical, int min_level,
+                                 int32_t *codes, int32_t *mask_pos) {
+  orc_tree_t *t = (orc_tree_t *)p;
+  int nm = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t id = ids[i];
+    if (id == 0) { codes[i] = -1; mask_pos[nm++] = i; }
+    else if (id < t->non_leaf_offset && id >= 0 && t->id_to_code[id] >= 0)
+      codes[i] = (hierarchical && level >= min_level) ? jtm_ancestor_code(t->id_to_code[id], level) : t->id_to_code[id];
+    else {
+      int32_t c = (int32_t)((uint32_t)id - (uint32_t)t->non_leaf_offset);
+      codes[i] = c > t->max_code ? -1 : c;
+    }
+  }
+  return nm;
+}
+
+/* TreeLearning.aggregateWeights (J/optim/TreeLearning.scala:152-174) for one item and one child:
+ * walk child -> up to (excl.) current node; each step = one forward over the item's rows and a
+ * sequential float sum of the logits (Tensor.sum).  row_ids: [n_rows * L] raw item ids. */
+static float jtm_aggregate(orc_tree_t *t, void *din, const int32_t *row_ids, int n_rows, int L, int32_t current_node,
+                           int32_t child, int level, int hierarchical, int min_level, int use_mask) {
+  if (n_rows == 0) return -1e6f;
+  float weights = 0.0f;
+  int32_t node = child;
+  int lv = level;
+  int32_t *codes = (int32_t *)malloc(sizeof(int32_t) * n_rows);
+  int32_t *seqs = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_rows * L);
+  int32_t *mask = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_rows * L);
+  float *out = (float *)malloc(sizeof(float) * n_rows);
+  while (node > current_node) {
+    for (int i = 0; i < n_rows; i++) codes[i] = node;
+    int nm = orc_jtm_id_to_code_with_mask(t, row_ids, n_rows * L, lv, hierarchical, min_level, seqs, mask);
+    if (!use_mask) nm = 0;
+    orc_din_forward_f32(din, codes, seqs, mask, nm, n_rows, out);
+    float score = 0.0f;
+    for (int i = 0; i < n_rows; i++) score += out[i];   /* DenseTensorMath.scala:395-406, sequential */
+    weights += score;
+    node = (node - 1) / 2;
+    lv -= 1;
+  }
+  free(codes); free(seqs); free(mask); free(out);
+  return weights;
+}
+
+/* child weights of every item of ONE gap step.  items[n]: item ids; row_off[n+1] / row_ids: the item's
+ * training rows (itemSequenceMap, TreeLearning.scala:34-46); item_node[n]: node (at old_level) the item
+ * currently sits in.  weights[n * nchild], child order = JTMTree.getChildrenAtLevel (J/tree/JTMTree.scala:53-57). */
+int orc_jtm_child_weights(void *tree, void *din, const int32_t *items, const int64_t *row_off, const int32_t *row_ids,
+                          const int32_t *item_node, int64_t n, int L, int old_level, int level, int hierarchical,
+                          int min_level, int use_mask, float *weights) {
+  orc_tree_t *t = (orc_tree_t *)tree;
+  const int nchild = 1 << (level - old_level);
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t first = ((int64_t)item_node[i] << (level - old_level)) + nchild - 1;   /* leftmost descendant */
+    for (int c = 0; c < nchild; c++)
+      weights[i * nchild + c] = jtm_aggregate(t, din, row_ids + row_off[i] * L, (int)(row_off[i + 1] - row_off[i]), L,
+                                              item_node[i], (int32_t)(first + c), level, hierarchical, min_level, use_mask);
+  }
+  return 0;
+}
+
+/*
+ * getChildrenProjection minus the scoring (J/optim/TreeLearning.scala:48-97) for ONE parent node:
+ * sortNodeWeights (stable, descending, :137-150), first choice = best child (:66-71), reBalance (:217-265).
+ * items[n] (in the order the reference would iterate them), weights[n * nchild], old_node[n] =
+ * tree.getAncestorAtLevel(item, level).  out_node[n] = assigned child code, or -1 when the greedy loop
+ * drops the item (every remaining candidate already processed).
+ */
+int orc_jtm_rebalance(const int32_t *items, const float *weights, const int32_t *old_node, int64_t n, int32_t node,
+                      int old_level, int level, int max_assign, int32_t *out_node) {
+  const int nchild = 1 << (level - old_level);
+  const int64_t first = ((int64_t)node << (level - old_level)) + nchild - 1;
+  /* candidateNodeWeights(item): children sorted by weight desc, stable */
+  int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * nchild);
+  int32_t *order = (int32_t *)malloc(sizeof(int32_t) * nchild);
+  for (int64_t i = 0; i < n; i++) {
+    stable_argsort_desc_f32(weights + i * nchild, order, nchild);
+    for (int c = 0; c < nchild; c++) cand[i * nchild + c] = order[c];
+  }
+  /* per child: member list of (item index, weight, nextWeightIdx) */
+  typedef struct { int64_t it; float w; int next; } info_t;
+  info_t **lst = (info_t **)calloc(nchild, sizeof(info_t *));
+  int64_t *cnt = (int64_t *)calloc(nchild, sizeof(int64_t)), *capv = (int64_t *)calloc(nchild, sizeof(int64_t));
+  uint8_t *present = (uint8_t *)calloc(nchild, 1), *processed = (uint8_t *)calloc(nchild, 1);
+#define PUSH(c, IT, W, NX) do { if (cnt[c] == capv[c]) { capv[c] = capv[c] ? capv[c] * 2 : 16; lst[c] = (info_t *)realloc(lst[c], sizeof(info_t) * capv[c]); } \
+                                 lst[c][cnt[c]].it = (IT); lst[c][cnt[c]].w = (W); lst[c][cnt[c]].next = (NX); cnt[c]++; present[c] = 1; } while (0)
+  for (int64_t i = 0; i < n; i++) { int c = cand[i * nchild]; PUSH(c, i, weights[i * nchild + c], 1); }
+  for (;;) {
+    /* getMaxNode (:203-215): first child in order with the largest member count among unprocessed, present ones */
+    int64_t best = -1; int bc = 0;
+    for (int c = 0; c < nchild; c++) {
+      int64_t v = (!processed[c] && present[c]) ? cnt[c] : -1;
+      if (c == 0 || v > best) { best = v; bc = c; }
+    }
+    if (best <= max_assign) break;
+    processed[bc] = 1;
+    /* sortBy (moved?, weight desc), stable (:240-242) */
+    const int64_t m = cnt[bc];
+    info_t *src = lst[bc];
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * m), *tmp = (int64_t *)malloc(sizeof(int64_t) * m);
+    for (int64_t i = 0; i < m; i++) idx[i] = i;
+    const int32_t this_code = (int32_t)(first + bc);
+    for (int64_t w = 1; w < m; w *= 2) {
+      for (int64_t lo = 0; lo < m; lo += 2 * w) {
+        int64_t mid = lo + w < m ? lo + w : m, hi = lo + 2 * w < m ? lo + 2 * w : m, a = lo, b = mid, o = lo;
+        while (a < mid && b < hi) {
+          const info_t *x = &src[idx[a]], *y = &src[idx[b]];
+          int mx = old_node[x->it] != this_code, my = old_node[y->it] != this_code;
+          int cmp = mx != my ? (mx < my ? -1 : 1) : java_float_compare(y->w, x->w);   /* false < true; weight reversed */
+          if (cmp > 0) tmp[o++] = idx[b++]; else tmp[o++] = idx[a++];
+        }
+        while (a < mid) tmp[o++] = idx[a++];
+        while (b < hi) tmp[o++] = idx[b++];
+      }
+      memcpy(idx, tmp, sizeof(int64_t) * m);
+    }
+    info_t *sorted = (info_t *)malloc(sizeof(info_t) * m);
+    for (int64_t i = 0; i < m; i++) sorted[i] = src[idx[i]];
+    free(idx); free(tmp);
+    cnt[bc] = max_assign;
+    memcpy(lst[bc], sorted, sizeof(info_t) * max_assign);
+    for (int64_t i = max_assign; i < m; i++) {   /* redundant items, in order */
+      const info_t it = sorted[i];
+      for (int k = it.next; k < nchild; k++) {
+        int c = cand[it.it * nchild + k];
+        if (!processed[c]) { PUSH(c, it.it, weights[it.it * nchild + c], k + 1); break; }
+      }
+    }
+    free(sorted);
+  }
+#undef PUSH
+  for (int64_t i = 0; i < n; i++) out_node[i] = -1;
+  for (int c = 0; c < nchild; c++)
+    for (int64_t k = 0; k < cnt[c]; k++) out_node[lst[c][k].it] = (int32_t)(first + c);
+  for (int c = 0; c < nchild; c++) free(lst[c]);
+  free(lst); free(cnt); free(capv); free(present); free(processed); free(cand); free(order);
+  (void)items;
+  return 0;
+}

@@ -69,6 +69,10 @@ def lib():
                                               C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p, f32p]
         L.orc_tdm_recommend_batch.argtypes = [C.c_void_p, C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_int, i32p, f32p, i32p]
+        L.orc_jtm_child_weights.argtypes = [C.c_void_p, C.c_void_p, i32p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        L.orc_jtm_rebalance.argtypes = [i32p, f32p, i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]
+        L.orc_jtm_id_to_code_with_mask.argtypes = [C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p]
         L.orc_lower_log2.argtypes = [C.c_int]
         L.orc_upper_log2.argtypes = [C.c_int]
         L.orc_otm_beam_nodes.argtypes = [i32p, f64p, C.c_int, C.c_int, C.c_int, i32p]
@@ -284,3 +288,26 @@ def softmax_backward(out, gout):
     lib().orc_softmax_backward_f64(_p(out, f64p), _p(gout, f64p), _p(gin, f64p), int(np.prod(out.shape[:-1])),
                                    out.shape[-1])
     return gin
+
+
+i64p = C.POINTER(C.c_int64)
+
+
+def jtm_child_weights(tree, din, items, row_off, row_ids, item_node, L, old_level, level, hierarchical=False,
+                      min_level=0, use_mask=True):
+    items, item_node, row_ids = _i32(items), _i32(item_node), _i32(row_ids)
+    row_off = np.ascontiguousarray(row_off, np.int64)
+    n = items.size
+    w = np.empty((n, 1 << (level - old_level)), np.float32)
+    lib().orc_jtm_child_weights(tree.h, din.h, _p(items, i32p), _p(row_off, i64p), _p(row_ids, i32p), _p(item_node, i32p),
+                                n, L, old_level, level, int(hierarchical), min_level, int(use_mask), _p(w, f32p))
+    return w
+
+
+def jtm_rebalance(items, weights, old_node, node, old_level, level, max_assign):
+    items, old_node = _i32(items), _i32(old_node)
+    weights = np.ascontiguousarray(weights, np.float32)
+    out = np.empty(items.size, np.int32)
+    lib().orc_jtm_rebalance(_p(items, i32p), _p(weights, f32p), _p(old_node, i32p), items.size, int(node), old_level,
+                            level, int(max_assign), _p(out, i32p))
+    return out

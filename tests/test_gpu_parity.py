@@ -318,3 +318,60 @@ def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk):
     for u in range(seqs.shape[0]):
         assert np.array_equal(np.sort(bsc[u, :k])[::-1], sc[u, :k])
     eng.close()
+
+
+# --------------------------------------------------------------------------- JTM tree learning
+def _jtm_problem(rng, fixture_tree, n_rows_max=6):
+    items = np.sort(fixture_tree["leaf_ids"])
+    rows = {}
+    for it in items.tolist():
+        k = int(rng.integers(0, n_rows_max))
+        if k and rng.random() > 0.1:                      # ~10 % of the items never appear as a target
+            r = rng.choice(items, (k, 10)).astype(np.int32)
+            r[:, :2][rng.random((k, 2)) < 0.4] = 0
+            rows[it] = r.reshape(-1)
+    return items, rows
+
+
+@pytest.mark.parametrize("hierarchical", [False, True])
+def test_jtm_child_weights_and_assignment(engine_fixture, oracle, oracle_tree, oracle_din32, fixture_tree, hierarchical):
+    from dismember_amd.jtm import JTM
+    rng = np.random.default_rng(31)
+    items, rows = _jtm_problem(rng, fixture_tree)
+    jtm = JTM(engine_fixture, fixture_tree["leaf_ids"], fixture_tree["leaf_codes"], 12, rows, gap=2, seq_len=10,
+              hierarchical=hierarchical, min_level=4)
+    # one gap step in the middle of the tree: items spread over the level-4 nodes of their current codes
+    old_level, level = 4, 6
+    item_node = JTM.ancestor_at_level(jtm.item_code, old_level)
+    w_gpu = jtm.child_weights(item_node, old_level, level)
+    w_ref = oracle.jtm_child_weights(oracle_tree, oracle_din32, jtm.items, jtm.row_off, jtm.row_ids, item_node, 10,
+                                     old_level, level, hierarchical=hierarchical, min_level=4)
+    seen = np.diff(jtm.row_off) > 0
+    assert (w_gpu[~seen] == -1e6).all() and (w_ref[~seen] == -1e6).all()
+    nrows = np.diff(jtm.row_off)[seen][:, None]
+    assert (np.abs(w_gpu[seen] - w_ref[seen]) <= nrows * 2 * (ATOL + RTOL * np.abs(w_ref[seen] / np.maximum(nrows, 1)))).all()
+    # assignment logic: product == oracle, bit-exact, when both are fed the SAME (GPU) weights
+    old_node = JTM.ancestor_at_level(jtm.item_code, level)
+    for node in np.unique(item_node)[:6]:
+        grp = np.flatnonzero(item_node == node)
+        a = jtm.rebalance(w_gpu[grp], old_node[grp], int(node), old_level, level, 1 << (12 - level))
+        b = oracle.jtm_rebalance(jtm.items[grp], w_gpu[grp], old_node[grp], int(node), old_level, level, 1 << (12 - level))
+        assert np.array_equal(a, b)
+
+
+def test_jtm_optimize_end_to_end(engine_fixture, oracle, oracle_tree, oracle_din32, fixture_tree):
+    """jtm/src/test/scala/JtmSpec.scala:37-51: projection covers every item once, codes in the leaf range;
+    plus: identical to the oracle-driven optimisation for (nearly) every item."""
+    from dismember_amd.jtm import JTM
+    rng = np.random.default_rng(32)
+    items, rows = _jtm_problem(rng, fixture_tree, n_rows_max=4)
+    jtm = JTM(engine_fixture, fixture_tree["leaf_ids"], fixture_tree["leaf_codes"], 12, rows, gap=2, seq_len=10)
+    proj = jtm.optimize()
+    assert len(proj) == 3706 and set(proj) == set(fixture_tree["leaf_ids"].tolist())
+    codes = np.array(list(proj.values()))
+    assert codes.min() >= 2 ** 12 - 1 and codes.max() <= 2 ** 13 - 2
+    assert np.bincount(codes).max() == 1                           # one item per leaf
+    ref = jtm.optimize(weight_fn=lambda node, ol, lv: oracle.jtm_child_weights(
+        oracle_tree, oracle_din32, jtm.items, jtm.row_off, jtm.row_ids, node, 10, ol, lv))
+    same = sum(int(proj[i] == ref[i]) for i in proj)
+    assert same >= 0.9 * len(proj), same

@@ -192,3 +192,18 @@ def test_otm_beam_search_structure(oracle, oracle_din64, fixture_otm_mapping):
     n2i = np.full(8191, -1, np.int32); n2i[m[:, 1]] = m[:, 0]
     items, scores = oracle.otm_finalize(ids, sc, n2i, 3)
     assert len(items) == 3 and (np.diff(scores) <= 0).all()
+
+
+def test_jtm_rebalance_respects_capacity_and_preferences(oracle):
+    """Structural invariants of reBalance (jtm/src/test/scala/JtmSpec.scala:37-51): every node within its
+    capacity, every item assigned to one of its parent's descendants, unconstrained items keep their argmax."""
+    rng = np.random.default_rng(1)
+    n, gap = 200, 2
+    w = rng.normal(size=(n, 4)).astype(np.float32)
+    w[:20] = -1e6                                     # items never seen as a target (TreeLearning.scala:160)
+    old = rng.integers(3, 7, n).astype(np.int32)
+    out = oracle.jtm_rebalance(np.arange(n), w, old, 0, 0, gap, 64)
+    assert ((out >= 3) & (out <= 6)).all()
+    assert np.bincount(out - 3, minlength=4).max() <= 64
+    big = oracle.jtm_rebalance(np.arange(n), w, old, 0, 0, gap, 1000)
+    assert np.array_equal(big[20:], 3 + w[20:].argmax(1))
