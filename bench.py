@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=10)
     ap.add_argument("--cpu-users", type=int, default=-1, help="oracle sample size (-1 auto, 0 skip)")
     ap.add_argument("--rho", type=float, default=0.95, help="parent-child correlation of the synthetic node embeddings")
+    ap.add_argument("--big", type=int, default=1, help="also time the 10M-item depth-24 tree (BASELINE metric's catalogue size); 0 = skip")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
     return ap.parse_args()
 
@@ -202,7 +203,50 @@ def main():
             same = sum(int(cnt[u] == ocnt[u] and np.array_equal(ids[u, :cnt[u]], oids[u, :ocnt[u]]))
                        for u in range(len(ocnt)))
             res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
-        print(json.dumps(res))
+        res_main = res
+    # ---- extra: the 10M-item depth-24 catalogue the metric names (17.2 GB table, replicated per GPU) ----
+    big = None
+    if a.big and (a.items, a.depth) == (1_000_000, 20):
+        eng.dev_free(d_seq); eng.dev_free(d_ids); eng.dev_free(d_sc); eng.dev_free(d_cnt)
+        eng.close()
+        depth2, items2 = 24, 10_000_000
+        ni2 = (1 << (depth2 + 1)) - 1
+        tree2 = synth.make_tree(items2, depth2, np.random.default_rng(synth.SEED))
+        seqs2 = synth.make_users(tree2["leaf_ids"], U, L, np.random.default_rng(synth.SEED + 101 + rank))
+        eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+        eng.load_tree(tree2["codes"], tree2["ids"], tree2["is_leaf"], depth2)
+        eng.load_id_maps(tree2["leaf_ids"], tree2["leaf_codes"])
+        eng.load_weights_din_synthetic(E, ni2, synth.SEED, tree_depth=depth2, rho=a.rho)
+        d_seq = eng.dev_alloc(U * L * 4); d_ids = eng.dev_alloc(U * a.topk * 4)
+        d_sc = eng.dev_alloc(U * a.topk * 4); d_cnt = eng.dev_alloc(U * 4)
+        eng.h2d(d_seq, seqs2)
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync(); eng.timing_reset(); barrier(); sync()
+        t0 = time.perf_counter()
+        nst = max(2, a.steps // 2)
+        for _ in range(nst):
+            eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync(); barrier()
+        dt2 = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        nl2, kms2 = eng.timing_get()
+        rows2 = eng.last_scored_rows()
+        big = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (17.2 GB table)"
+                           % (items2, depth2, E, a.beam, a.topk),
+               "users_per_s": world * U * nst / dt2, "steps": nst, "ms_per_step": dt2 / nst * 1e3,
+               "scored_rows_per_user": rows2 / U,
+               "roofline_frac": rows2 * 2 * (E * E + 2 * L * E + E) / (kms2 / max(nl2, 1) * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS}
+        if a.recall_users > 0 and rank == 0:
+            nr = min(a.recall_users, 16)
+            ids2 = np.empty((U, a.topk), np.int32); cnt2 = np.empty(U, np.int32)
+            eng.d2h(ids2, d_ids); eng.d2h(cnt2, d_cnt)
+            bids, _, bcnt = eng.tdm_bruteforce_topk(seqs2[:nr], a.topk)
+            big["recall_at_%d_vs_bruteforce" % a.topk] = float(np.mean(
+                [len(set(ids2[u, :cnt2[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]))
+            big["recall_users"] = nr
+    if rank == 0:
+        if big is not None:
+            res_main["extra_10m_item_tree"] = big
+        print(json.dumps(res_main))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
