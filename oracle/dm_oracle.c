@@ -28,18 +28,26 @@
 #define REAL float
 #define SUFFIX f32
 #define REAL_EXP expf
+#define REAL_LOG logf
+#define REAL_SQRT sqrtf
 #include "din_body.inc"
 #undef REAL
 #undef SUFFIX
 #undef REAL_EXP
+#undef REAL_LOG
+#undef REAL_SQRT
 
 #define REAL double
 #define SUFFIX f64
 #define REAL_EXP exp
+#define REAL_LOG log
+#define REAL_SQRT sqrt
 #include "din_body.inc"
 #undef REAL
 #undef SUFFIX
 #undef REAL_EXP
+#undef REAL_LOG
+#undef REAL_SQRT
 
 /* --------------------------------------------------- Java number orderings */
 

@@ -45,6 +45,14 @@ def lib():
         L.orc_din_destroy_f64.argtypes = [C.c_void_p]
         L.orc_din_forward_f32.argtypes = [C.c_void_p, i32p, i32p, i32p, C.c_int64, C.c_int64, f32p]
         L.orc_din_forward_f64.argtypes = [C.c_void_p, i32p, i32p, i32p, C.c_int64, C.c_int64, f64p]
+        L.orc_din_train_grads_f32.restype = C.c_float
+        L.orc_din_train_grads_f32.argtypes = [C.c_void_p, i32p, i32p, i32p, C.c_int64, f32p, C.c_int64, f32p]
+        L.orc_din_train_grads_f64.restype = C.c_double
+        L.orc_din_train_grads_f64.argtypes = [C.c_void_p, i32p, i32p, i32p, C.c_int64, f64p, C.c_int64, f64p]
+        L.orc_adam_step_f32.argtypes = [f32p, f32p, f32p, f32p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.POINTER(C.c_int)]
+        L.orc_adam_step_f64.argtypes = [f64p, f64p, f64p, f64p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.POINTER(C.c_int)]
         L.orc_softmax_f32.argtypes = [f32p, f32p, C.c_int, C.c_int]
         L.orc_softmax_f64.argtypes = [f64p, f64p, C.c_int, C.c_int]
         L.orc_softmax_backward_f64.argtypes = [f64p, f64p, f64p, C.c_int, C.c_int]
@@ -121,6 +129,19 @@ class Din:
         if rc != 0:
             raise IndexError("embeddingLookup failed at row %d" % (-rc - 1))
         return out
+
+    def train_grads(self, codes, seqs, pad_flat, labels, grad=None):
+        """One worker's trainBatch: returns (mean BCE loss, gradient in the compact-vector layout)."""
+        codes = _i32(codes).ravel()
+        seqs = _i32(seqs).reshape(-1)
+        pad = _i32([] if pad_flat is None else pad_flat).ravel()
+        lab = np.ascontiguousarray(labels, dtype=self.dtype).ravel()
+        if grad is None:
+            grad = np.zeros(self.w.size, self.dtype)
+        fn = getattr(lib(), "orc_din_train_grads_" + self.sfx)
+        loss = fn(self.h, _p(codes, i32p), _p(seqs, i32p), _p(pad, i32p), pad.size, _p(lab, self.ptr_t), codes.size,
+                  _p(grad, self.ptr_t))
+        return float(loss), grad
 
     @property
     def scorer_f32(self):
@@ -311,3 +332,19 @@ def jtm_rebalance(items, weights, old_node, node, old_level, level, max_assign):
     lib().orc_jtm_rebalance(_p(items, i32p), _p(weights, f32p), _p(old_node, i32p), items.size, int(node), old_level,
                             level, int(max_assign), _p(out, i32p))
     return out
+
+
+class Adam:
+    """Adam.optimize (scalann/.../optim/Adam.scala:19-73) on a flat numpy vector, state kept here."""
+
+    def __init__(self, n, dtype=np.float32, lr=1e-3, lrd=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.s = np.zeros(n, dtype)
+        self.r = np.zeros(n, dtype)
+        self.t = C.c_int(0)
+        self.hp = (lr, lrd, beta1, beta2, eps)
+        self.dtype = np.dtype(dtype)
+
+    def step(self, w, g):
+        pt = f32p if self.dtype == np.float32 else f64p
+        fn = lib().orc_adam_step_f32 if self.dtype == np.float32 else lib().orc_adam_step_f64
+        fn(_p(w, pt), _p(g, pt), _p(self.s, pt), _p(self.r, pt), w.size, *self.hp, C.byref(self.t))

@@ -207,3 +207,48 @@ def test_jtm_rebalance_respects_capacity_and_preferences(oracle):
     assert np.bincount(out - 3, minlength=4).max() <= 64
     big = oracle.jtm_rebalance(np.arange(n), w, old, 0, 0, gap, 1000)
     assert np.array_equal(big[20:], 3 + w[20:].argmax(1))
+
+
+def test_din_backward_matches_finite_differences(oracle):
+    """The restated backward (BCE + Linear/ReLU/Concat/Attention/Embedding) against central differences of an
+    independent float64 numpy forward."""
+    rng = np.random.default_rng(5)
+    E, L, NI, B = 16, 5, 63, 24
+    w = random_din_weights(rng, E, NI, np.float64, std=0.3, bias_std=0.3)
+    codes = rng.integers(0, NI, B).astype(np.int32)
+    seqs = rng.integers(0, NI, (B, L)).astype(np.int32)
+    seqs[rng.random((B, L)) < 0.2] = -1
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    y = (rng.random(B) < 0.4).astype(np.float64)
+    din = oracle.Din(w, E, L, NI)
+    loss, g = din.train_grads(codes, seqs, pad, y)
+
+    def f(wv):
+        x = numpy_din_forward(wv, E, L, NI, codes, seqs, pad)
+        return float(np.mean(np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))))
+    assert abs(loss - f(w)) < 1e-12
+    idx = np.concatenate([rng.choice(NI * E, 25, replace=False), NI * E + rng.choice(3 * E * E + 2 * E + 1, 40, replace=False),
+                          [w.size - 1]])
+    touched = set(codes.tolist()) | set(seqs[seqs >= 0].tolist())
+    for i in idx:
+        h = 1e-6
+        wp = w.copy(); wp[i] += h
+        wm = w.copy(); wm[i] -= h
+        num = (f(wp) - f(wm)) / (2 * h)
+        assert abs(num - g[i]) < 1e-7 + 1e-5 * abs(num), (i, num, g[i])
+        if i < NI * E and (i // E) not in touched:
+            assert g[i] == 0.0
+
+
+def test_adam_step_matches_formula(oracle):
+    rng = np.random.default_rng(6)
+    n = 1000
+    w = rng.normal(size=n); g = rng.normal(size=n) * 1e-2
+    w0 = w.copy()
+    opt = oracle.Adam(n, np.float64, lr=1e-3)
+    s = np.zeros(n); r = np.zeros(n)
+    for t in range(1, 4):
+        opt.step(w, g)
+        s = 0.9 * s + 0.1 * g; r = 0.999 * r + 0.001 * g * g
+        w0 = w0 - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * s / (np.sqrt(r) + 1e-8)   # eps after sqrt
+        assert np.abs(w - w0).max() < 1e-12
