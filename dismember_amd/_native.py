@@ -19,6 +19,11 @@ f32p = C.POINTER(C.c_float)
 u8p = C.POINTER(C.c_uint8)
 
 
+class AdamOpts(C.Structure):
+    _fields_ = [("lr", C.c_double), ("lr_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double)]
+
+
 class SearchOpts(C.Structure):
     _fields_ = [("beam", C.c_int), ("topk", C.c_int), ("use_mask", C.c_int), ("widen_consumed", C.c_int)]
 
@@ -46,6 +51,13 @@ SIGNATURES = {
     "dm_jtm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, f32p]),
     "dm_jtm_rebalance": (C.c_int, [C.c_void_p, f32p, i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]),
+    "dm_train_init": (C.c_int, [C.c_void_p, C.POINTER(AdamOpts)]),
+    "dm_train_forward_backward": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int64, f32p, C.c_int64, C.c_int, f32p]),
+    "dm_adam_step": (C.c_int, [C.c_void_p, C.c_float]),
+    "dm_train_download": (C.c_int, [C.c_void_p, C.c_int, f32p, C.c_int64]),
+    "dm_train_dense_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
+    "dm_train_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
+    "dm_train_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "dm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

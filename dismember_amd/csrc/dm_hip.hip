@@ -16,6 +16,7 @@
 
 #include "beam_kernel.hip.inc"
 #include "rows_kernel.hip.inc"
+#include "train_kernel.hip.inc"
 
 #define DM_VERSION 100
 
@@ -46,6 +47,16 @@ struct dm_ctx {
   float *d_b1 = nullptr, *d_w2 = nullptr;
   float b2 = 0.f;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
+  // training state (dm_train_init)
+  bool train_ready = false;
+  dm_adam_opts adam{};
+  int adam_t = 0;
+  float *d_grad = nullptr, *d_adam_s = nullptr, *d_adam_r = nullptr, *d_loss = nullptr;
+  f32x4 *d_attTA = nullptr, *d_w1aTA = nullptr, *d_w1bTA = nullptr;
+  unsigned *d_touch_bits = nullptr;
+  int32_t *d_touch_list = nullptr;
+  unsigned long long *d_touch_cnt = nullptr;
+  size_t touch_cap = 0;
   // measurement
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -242,6 +253,10 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
+  dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
+  dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
+  h->d_grad = h->d_adam_s = h->d_adam_r = h->d_loss = nullptr; h->d_attTA = h->d_w1aTA = h->d_w1bTA = nullptr;
+  h->d_touch_bits = nullptr; h->d_touch_list = nullptr; h->d_touch_cnt = nullptr; h->train_ready = false; h->touch_cap = 0;
   h->d_afrag = h->d_bfrag = nullptr; h->d_attA = h->d_w1aA = h->d_w1bA = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
 }
 
@@ -981,6 +996,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 }
 
 #include "jtm_host.hip.inc"
+#include "train_host.hip.inc"
 
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {

@@ -191,6 +191,33 @@ class Engine:
                                                  _p(ids, N.i32p), _p(sc, N.f32p), _p(cnt, N.i32p)))
         return ids, sc, cnt
 
+    # ---- training (row A12)
+    def train_init(self, lr=1e-3, lr_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        o = N.AdamOpts(lr, lr_decay, beta1, beta2, eps)
+        self._chk(N.lib().dm_train_init(self._h, C.byref(o)))
+
+    def train_forward_backward(self, codes, seqs, pad_flat_idx, labels):
+        codes = _i32(codes).ravel()
+        seqs = _i32(seqs)
+        B = codes.size
+        L = seqs.shape[-1] if seqs.ndim == 2 else seqs.size // B
+        seqs = seqs.ravel()
+        pad = _i32([] if pad_flat_idx is None else pad_flat_idx).ravel()
+        lab = np.ascontiguousarray(labels, np.float32).ravel()
+        loss = C.c_float(0)
+        self._chk(N.lib().dm_train_forward_backward(self._h, _p(codes, N.i32p), _p(seqs, N.i32p), _p(pad, N.i32p), pad.size,
+                                                    _p(lab, N.f32p), B, L, C.byref(loss)))
+        return loss.value
+
+    def adam_step(self, grad_scale=1.0):
+        self._chk(N.lib().dm_adam_step(self._h, float(grad_scale)))
+
+    def train_download(self, what="weights"):
+        n = self.num_index * self.E + 3 * self.E * self.E + 2 * self.E + 1
+        out = np.empty(n, np.float32)
+        self._chk(N.lib().dm_train_download(self._h, {"weights": 0, "grad": 1, "s": 2, "r": 3}[what], _p(out, N.f32p), n))
+        return out
+
     # ---- device-resident path (bench)
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

@@ -143,6 +143,30 @@ int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *r
 int dm_jtm_rebalance(dm_handle_t h, const float *weights, const int32_t *old_node, int64_t n, int32_t node, int old_level,
                      int level, int max_assign, int32_t *out_node);
 
+/* ---- training step (tdm/src/main/scala/com/mass/tdm/optim/LocalOptimizer.scala:58-187) ------------------
+ * One handle == one worker (the reference's per-thread model clone).  A step is
+ *   dm_train_forward_backward  == trainBatch (:139-162): zero-initialised gradients accumulate the mean-BCE
+ *                                  gradient of this worker's rows (BCECriterionWithLogits + Module.backward)
+ *   [exchange between workers]  == syncGradients (:164-187): sum over workers, then / n_workers
+ *   dm_adam_step(1/n_workers)   == Adam.optimize (scalann/.../optim/Adam.scala:19-73), DENSE over the whole
+ *                                  compact vector (untouched embedding rows still move through s, r), then
+ *                                  the gradient is zeroed (zeroGradParameters).
+ * f32 weights only. */
+typedef struct { double lr, lr_decay, beta1, beta2, eps; } dm_adam_opts;   /* reference defaults: 1e-3, 0, 0.9, 0.999, 1e-8 */
+int dm_train_init(dm_handle_t h, const dm_adam_opts *opts);
+int dm_train_forward_backward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
+                              int64_t n_pad, const float *labels, int64_t B, int L, float *loss);
+int dm_adam_step(dm_handle_t h, float grad_scale);
+/* what: 0 weights, 1 gradient, 2 Adam s, 3 Adam r — host copy of the full compact-layout vector (tests, checkpoints) */
+int dm_train_download(dm_handle_t h, int what, float *out, int64_t n);
+/* Gradient exchange for N workers on N GPUs: the dense block [att.W ; l1.W ; l1.b ; l2.W ; l2.b]
+ * is all-reduced in place through the returned device pointer (RCCL); embedding gradients are row-sparse:
+ * export this worker's unique touched rows (index + gradient row, device buffers), all-gather them, add the
+ * other workers' rows.  Replicas stay bit-identical because every rank applies the same sums in the same order. */
+int dm_train_dense_block(dm_handle_t h, float **d_ptr, int64_t *n);
+int dm_train_export_rows(dm_handle_t h, int32_t *d_rows, float *d_grads, int64_t cap, int64_t *n);   /* NULL buffers: size query */
+int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const float *d_grads, int64_t n);
+
 /* ---- device-resident variants (bench: inputs already in HBM when the clock starts) ---- */
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr);
 int dm_dev_free(dm_handle_t h, void *dptr);

@@ -375,3 +375,70 @@ def test_jtm_optimize_end_to_end(engine_fixture, oracle, oracle_tree, oracle_din
         oracle_tree, oracle_din32, jtm.items, jtm.row_off, jtm.row_ids, node, 10, ol, lv))
     same = sum(int(proj[i] == ref[i]) for i in proj)
     assert same >= 0.9 * len(proj), same
+
+
+# --------------------------------------------------------------------------- training step
+def _train_batch(rng, NI, B, L=10):
+    codes = rng.integers(0, NI, B).astype(np.int32)
+    seqs = rng.integers(0, NI, (B, L)).astype(np.int32)
+    seqs[rng.random((B, L)) < 0.2] = -1
+    seqs[0] = -1
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    return codes, seqs, pad, y
+
+
+@pytest.mark.parametrize("E,NI,B", [(16, 8191, 300), (128, 1023, 200), (32, 255, 1000)])
+def test_train_step_vs_oracle(oracle, fixture_w32, E, NI, B):
+    """trainBatch + Adam (LocalOptimizer.scala:139-162, Adam.scala:19-73): loss and gradients within tolerance of the
+    oracle's backward; the Adam update itself is bit-exact given the same gradient."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(E + B)
+    w = fixture_w32.copy() if (E, NI) == (16, 8191) else random_din_weights(rng, E, NI, std=0.2, bias_std=0.2)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    eng.train_init(lr=1e-3)
+    codes, seqs, pad, y = _train_batch(rng, NI, B)
+    loss = eng.train_forward_backward(codes, seqs, pad, y)
+    g = eng.train_download("grad")
+    odin = oracle.Din(w.copy(), E, 10, NI)
+    oloss, og = odin.train_grads(codes, seqs, pad, y)
+    assert abs(loss - oloss) <= 1e-5 + 1e-4 * abs(oloss)
+    # gradients: sums of B terms of mixed sign -> tolerance relative to the accumulated magnitude
+    tol = 2e-5 * np.abs(og).max() + 1e-4 * np.abs(og)
+    assert (np.abs(g - og) <= tol).all(), float(np.abs(g - og).max())
+    touched = np.zeros(NI, bool); touched[codes] = True; touched[seqs[seqs >= 0]] = True
+    assert (g[:NI * E].reshape(NI, E)[~touched] == 0).all()
+    # Adam: bit-exact against the restated update fed with the GPU gradient
+    eng.adam_step(1.0)
+    w1 = eng.train_download("weights")
+    ref = w.copy()
+    opt = oracle.Adam(ref.size, np.float32, lr=1e-3)
+    opt.step(ref, g.copy())
+    assert np.array_equal(w1, ref)
+    assert np.array_equal(eng.train_download("s"), opt.s) and np.array_equal(eng.train_download("r"), opt.r)
+    assert (eng.train_download("grad") == 0).all()
+    # the refreshed fragment copies serve the next forward: logits after the step == oracle forward on the new weights
+    odin2 = oracle.Din(w1.copy(), E, 10, NI)
+    assert close(eng.din_forward(codes, seqs, pad), odin2.forward(codes, seqs, pad)).all()
+    # a second step still tracks the oracle (state carried)
+    loss2 = eng.train_forward_backward(codes, seqs, pad, y)
+    oloss2, og2 = odin2.train_grads(codes, seqs, pad, y)
+    assert abs(loss2 - oloss2) <= 1e-5 + 1e-4 * abs(oloss2) and loss2 < loss
+    eng.close()
+
+
+def test_training_reduces_loss(fixture_w32):
+    """scalann's own training tests assert a decreasing loss (SampledSoftmaxLossTest.scala:42-53); same here."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(3)
+    eng = Engine(0)
+    eng.load_weights_din(random_din_weights(rng, 32, 511, std=0.1), 32, 511)
+    eng.train_init(lr=5e-3)
+    codes, seqs, pad, y = _train_batch(rng, 511, 2048)
+    losses = []
+    for _ in range(12):
+        losses.append(eng.train_forward_backward(codes, seqs, pad, y))
+        eng.adam_step()
+    assert losses[-1] < losses[0] - 0.03 and all(b < a + 1e-4 for a, b in zip(losses, losses[1:]))
+    eng.close()
