@@ -58,6 +58,11 @@ SIGNATURES = {
     "dm_train_dense_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "dm_train_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
     "dm_train_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "dm_tdm_make_train_batch": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64, C.c_int, i32p, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                          i32p, i32p, C.POINTER(C.c_uint32), f32p, C.c_int64, i64p]),
+    "dm_train_forward_backward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                f32p]),
+    "dm_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

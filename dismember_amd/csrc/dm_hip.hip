@@ -34,6 +34,7 @@ struct dm_ctx {
   int32_t *d_node_id = nullptr, *d_id_to_code = nullptr, *d_leaf_codes = nullptr;
   int32_t non_leaf_offset = -1, max_code = -1;
   std::vector<int32_t> h_id_to_code;
+  std::vector<uint32_t> h_exists;      // host copy of the existence bitmap (negative sampling)
   // weights
   bool w_loaded = false;
   int dtype = DM_F32, embed = 0;
@@ -317,6 +318,7 @@ int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_id
   HIPCHK(h, hipMemcpy(h->d_node_id, nid.data(), n_slots * 4, hipMemcpyHostToDevice));
   if (!leaf_codes.empty())
     HIPCHK(h, hipMemcpy(h->d_leaf_codes, leaf_codes.data(), leaf_codes.size() * 4, hipMemcpyHostToDevice));
+  h->h_exists = ex;
   h->n_slots = n_slots; h->n_leaf_nodes = (int64_t)leaf_codes.size(); h->max_level = max_level;
   h->leaves_at_max_only = at_max_only; h->tree_loaded = true;
   return DM_OK;

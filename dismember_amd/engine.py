@@ -209,6 +209,32 @@ class Engine:
                                                     _p(lab, N.f32p), B, L, C.byref(loss)))
         return loss.value
 
+    def make_train_batch(self, seq_item_ids, target_item_ids, neg_counts, start_level=1, seed=0, use_mask=True):
+        """NegativeSampler.sample + MiniBatch.convert: (codes [R], seqs [R, L], rowmask [R], labels [R])."""
+        seq = _i32(seq_item_ids)
+        tgt = _i32(target_item_ids).ravel()
+        T, L = seq.shape
+        neg = _i32(neg_counts)
+        n = C.c_int64(0)
+        self._chk(N.lib().dm_tdm_make_train_batch(self._h, _p(seq, N.i32p), _p(tgt, N.i32p), T, L, _p(neg, N.i32p), neg.size,
+                                                  int(start_level), int(seed), int(bool(use_mask)), None, None, None, None, 0,
+                                                  C.byref(n)))
+        R = n.value
+        codes = np.empty(max(R, 1), np.int32); seqs = np.empty((max(R, 1), L), np.int32)
+        mask = np.empty(max(R, 1), np.uint32); lab = np.empty(max(R, 1), np.float32)
+        self._chk(N.lib().dm_tdm_make_train_batch(self._h, _p(seq, N.i32p), _p(tgt, N.i32p), T, L, _p(neg, N.i32p), neg.size,
+                                                  int(start_level), int(seed), int(bool(use_mask)), _p(codes, N.i32p),
+                                                  _p(seqs, N.i32p), mask.ctypes.data_as(C.POINTER(C.c_uint32)), _p(lab, N.f32p),
+                                                  R, C.byref(n)))
+        R = n.value
+        return codes[:R], seqs[:R], mask[:R], lab[:R]
+
+    @staticmethod
+    def rowmask_to_flat(mask, L):
+        """Row bit masks -> the flat index list Module.forward takes (Mask.scala:27-32)."""
+        i, j = np.nonzero((mask[:, None] >> np.arange(L, dtype=np.uint32)[None, :]) & 1)
+        return (i * L + j).astype(np.int32)
+
     def adam_step(self, grad_scale=1.0):
         self._chk(N.lib().dm_adam_step(self._h, float(grad_scale)))
 

@@ -167,6 +167,19 @@ int dm_train_dense_block(dm_handle_t h, float **d_ptr, int64_t *n);
 int dm_train_export_rows(dm_handle_t h, int32_t *d_rows, float *d_grads, int64_t cap, int64_t *n);   /* NULL buffers: size query */
 int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const float *d_grads, int64_t n);
 
+/* Level-wise negative sampling + batch expansion (uniform mode): NegativeSampler.sample
+ * (tdm/.../utils/NegativeSampler.scala:76-114,146-158) + MiniBatch.convert (tdm/.../dataset/MiniBatch.scala:49-88).
+ * seq_item_ids [T*L], target_item_ids [T]; neg_counts = model.layer_negative_counts (>= max_level+1 entries).
+ * Rows per target = sum_{l=start_level}^{max_level} (1 + neg_counts[l]); call with out_codes == NULL for the size.
+ * out_rowmask bit j = history position j masked.  Seeded (the reference is not): distributional parity only. */
+int dm_tdm_make_train_batch(dm_handle_t h, const int32_t *seq_item_ids, const int32_t *target_item_ids, int64_t T, int L,
+                            const int32_t *neg_counts, int n_counts, int start_level, uint64_t seed, int use_mask,
+                            int32_t *out_codes, int32_t *out_seqs, uint32_t *out_rowmask, float *out_labels, int64_t cap,
+                            int64_t *n_rows);
+int dm_train_forward_backward_dev(dm_handle_t h, const int32_t *d_codes, const int32_t *d_seqs, const uint32_t *d_rowmask,
+                                  const float *d_labels, int64_t B, int L, float *loss);
+int dm_memcpy_d2d(dm_handle_t h, void *dst, const void *src, size_t bytes);
+
 /* ---- device-resident variants (bench: inputs already in HBM when the clock starts) ---- */
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr);
 int dm_dev_free(dm_handle_t h, void *dptr);

@@ -51,3 +51,62 @@ def test_two_rank_gloo_sharding():
     assert all(p.exitcode == 0 for p in procs)
     for r, slowest, shape, ordered in out:
         assert slowest == 2.0 and shape == (101, 3) and ordered
+
+
+# ---- gradient exchange protocol of the data-parallel trainer (2 gloo ranks, numpy-backed fake engines) ----
+class _FakePort:
+    """Stands in for EngineGradPort: a dense block and a row-sparse embedding gradient held in torch CPU tensors."""
+
+    def __init__(self, torch, rank, n_rows=50, E=4):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.torch = torch
+        self.dense_block = torch.randn(37, generator=g)
+        self.table = torch.zeros(n_rows, E)
+        idx = torch.randperm(n_rows, generator=g)[:12]
+        self.table[idx] = torch.randn(12, E, generator=g)
+        self.touched = idx.to(torch.int32)
+
+    def dense(self):
+        return self.dense_block.clone()
+
+    def set_dense(self, t):
+        self.dense_block = t.clone()
+
+    def export_rows(self):
+        return self.touched, self.table[self.touched.long()].clone()
+
+    def add_rows(self, rows, grads):
+        self.table.index_add_(0, rows.long(), grads)
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    from dismember_amd import sharding
+    from dismember_amd.trainer import exchange_gradients
+    dist, r, w, _ = sharding.init_distributed("gloo")
+    ports = [_FakePort(torch, k) for k in range(world)]        # every rank can rebuild every rank's local gradient
+    mine = ports[r]
+    n = exchange_gradients(mine, dist, torch)
+    want_dense = sum(p.dense_block for p in [_FakePort(torch, k) for k in range(world)])
+    want_table = sum(p.table for p in [_FakePort(torch, k) for k in range(world)])
+    q.put((r, n, bool(torch.allclose(mine.dense_block, want_dense)), bool(torch.allclose(mine.table, want_table))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(n == 2 and dense_ok and table_ok for _, n, dense_ok, table_ok in out)
