@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=10)
     ap.add_argument("--cpu-users", type=int, default=-1, help="oracle sample size (-1 auto, 0 skip)")
     ap.add_argument("--rho", type=float, default=0.95, help="parent-child correlation of the synthetic node embeddings")
+    ap.add_argument("--train", type=int, default=1, help="also time a training step (0 = skip)")
     ap.add_argument("--big", type=int, default=1, help="also time the 10M-item depth-24 tree (BASELINE metric's catalogue size); 0 = skip")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
     return ap.parse_args()
@@ -204,6 +205,30 @@ def main():
                        for u in range(len(ocnt)))
             res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
         res_main = res
+    # ---- extra: one data-parallel training step on the same catalogue (rows A10 + A12; every rank = one worker) ----
+    train = None
+    if a.train and (a.items, a.depth) == (1_000_000, 20):
+        from dismember_amd.trainer import TDMTrainer
+        neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 19, 22, 25, 30], np.int32)   # configs/tdm.conf
+        per = int(sum(1 + neg[l] for l in range(1, depth + 1)))
+        Tt = max(1, 8192 // per)                        # total_batch_size 8192 expanded rows per worker
+        tr = TDMTrainer(eng, neg, lr=1e-4, dist=dist, torch=torch, seed=synth.SEED)
+        trng = np.random.default_rng(synth.SEED + 7 + rank)
+        tseq = synth.make_users(tree["leaf_ids"], Tt, L, trng)
+        ttgt = trng.choice(tree["leaf_ids"], Tt).astype(np.int32)
+        tr.step(tseq, ttgt)
+        sync(); barrier()
+        t0 = time.perf_counter()
+        nts = 5
+        for _ in range(nts):
+            tloss = tr.step(tseq, ttgt)
+        sync(); barrier()
+        dtt = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        nparam = num_index * E + 3 * E * E + 2 * E + 1
+        train = {"workload": "TDM train step: %d targets -> %d expanded rows per worker (level-wise negatives), DIN fwd+bwd, "
+                             "gradient exchange, dense Adam over %d parameters" % (Tt, Tt * per, nparam),
+                 "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
+                 "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world}
     # ---- extra: the 10M-item depth-24 catalogue the metric names (17.2 GB table, replicated per GPU) ----
     big = None
     if a.big and (a.items, a.depth) == (1_000_000, 20):
@@ -246,6 +271,8 @@ def main():
     if rank == 0:
         if big is not None:
             res_main["extra_10m_item_tree"] = big
+        if train is not None:
+            res_main["extra_train_step"] = train
         print(json.dumps(res_main))
     if dist is not None:
         dist.barrier()
