@@ -47,6 +47,8 @@ SIGNATURES = {
     "dm_tdm_beam_search_trace": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.POINTER(SearchOpts), i32p, f32p,
                                            i32p, C.c_int, i32p, f32p, i32p]),
     "dm_otm_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
+    "dm_otm_beam_search_trace": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p, C.c_int,
+                                           i32p, f32p, i32p]),
     "dm_tdm_bruteforce_topk": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
     "dm_jtm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, f32p]),

@@ -863,9 +863,9 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
                          trace_codes, trace_scores, trace_counts);
 }
 
-int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
-                       int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
-  if (!h) return DM_ERR_INVALID;
+static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                           int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels, int32_t *tc,
+                           float *ts, int32_t *tn) {
   if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_otm_beam_search: weights not loaded");
   if (!seq_codes || !out_node_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
     return fail(h, DM_ERR_INVALID, "dm_otm_beam_search: bad arguments");
@@ -879,10 +879,17 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
   int rc = plan_search(h, beam, U, L, leaf_level - level, false, &pl);
   if (rc != DM_OK) return rc;
   const int stride = 2 * beam;
-  int32_t *d_seq = nullptr, *d_ids = nullptr, *d_counts = nullptr;
-  float *d_scores = nullptr;
+  int32_t *d_seq = nullptr, *d_ids = nullptr, *d_counts = nullptr, *d_tc = nullptr, *d_tn = nullptr;
+  float *d_scores = nullptr, *d_ts = nullptr;
   do {
     if ((rc = ensure_ws(h, (size_t)pl.grid * pl.nteams * pl.ws_cap * 16)) != DM_OK) break;
+    if (tn) {
+      const size_t nt = (size_t)U * max_levels;
+      if ((rc = dm_alloc(h, (void **)&d_tc, nt * pl.cap * 4)) != DM_OK) break;
+      if ((rc = dm_alloc(h, (void **)&d_ts, nt * pl.cap * 4)) != DM_OK) break;
+      if ((rc = dm_alloc(h, (void **)&d_tn, nt * 4)) != DM_OK) break;
+      if (hipMemsetAsync(d_tn, 0, nt * 4, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "memset failed"); break; }
+    }
     if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
     if ((rc = dm_alloc(h, (void **)&d_ids, (size_t)U * stride * 4)) != DM_OK) break;
     if ((rc = dm_alloc(h, (void **)&d_scores, (size_t)U * stride * 4)) != DM_OK) break;
@@ -900,7 +907,15 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
     p.nteams = pl.nteams; p.cap = pl.cap; p.pcap = pl.pcap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
     p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
     p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
+    p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = tn ? max_levels : 0;
     if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
+    if (tn) {
+      const size_t nt = (size_t)U * max_levels;
+      e = hipMemcpyAsync(tc, d_tc, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: trace download failed"); break; }
+    }
     e = hipMemcpyAsync(out_node_ids, d_ids, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
@@ -909,9 +924,25 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
     unsigned long long rows = 0;
     if (hipMemcpy(&rows, h->d_rows, 8, hipMemcpyDeviceToHost) == hipSuccess) h->last_rows = (int64_t)rows;
   } while (0);
-  dm_free_ptr(d_seq); dm_free_ptr(d_ids); dm_free_ptr(d_scores); dm_free_ptr(d_counts);
+  dm_free_ptr(d_seq); dm_free_ptr(d_ids); dm_free_ptr(d_scores); dm_free_ptr(d_counts); dm_free_ptr(d_tc); dm_free_ptr(d_ts); dm_free_ptr(d_tn);
   return rc;
 }
+
+int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                       int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, 0, nullptr, nullptr, nullptr);
+}
+
+int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                             int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels,
+                             int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
+  if (!h) return DM_ERR_INVALID;
+  if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_trace: bad trace arguments");
+  return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, max_levels, trace_codes,
+                         trace_scores, trace_counts);
+}
+
 
 // Brute force over every leaf with the same fused scorer (mode 2 of the beam kernel): the
 // build-defined oracle for recall@k.  Order: score descending, then leaf code ascending.

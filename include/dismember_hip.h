@@ -121,6 +121,12 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts);
 
+/* Same, dumping every level's scored candidates = OTMTree.beamSearchNodes (O/tree/OTMTree.scala:67-91), which OTM
+ * training consumes: trace_* [U * max_levels * cap] / [U * max_levels], cap = 2*beam rounded up to 16 (min 32). */
+int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                             int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels,
+                             int32_t *trace_codes, float *trace_scores, int32_t *trace_counts);
+
 /* ---- brute force over every leaf (build-defined recall@k oracle) ---- */
 int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
                            int32_t *out_item_ids, float *out_scores, int32_t *out_counts);

@@ -504,3 +504,89 @@ def test_tdm_trainer_single_worker(fixture_tree, fixture_w32):
     ids, sc, cnt = eng.tdm_beam_search(seqs[:4], 20, 10)
     assert (cnt == 10).all() and np.isfinite(sc).all()
     eng.close()
+
+
+# --------------------------------------------------------------------------- OTM training (rows A4 trace, A11, A12)
+def _otm_problem(rng, fixture_otm_mapping, U):
+    item2node = {int(a): int(b) for a, b in fixture_otm_mapping}
+    items = fixture_otm_mapping[:, 0]
+    seqs = rng.choice(items, (U, 10))
+    seqs[:, :2][rng.random((U, 2)) < 0.5] = 0
+    codes = np.array([[item2node.get(int(i), -1) for i in row] for row in seqs], np.int32)
+    targets = [[item2node[int(i)] for i in rng.choice(items, int(rng.integers(1, 4)), replace=False)] for _ in range(U)]
+    return codes, targets
+
+
+def test_otm_pseudo_targets_and_beam_nodes(fixture_w64, fixture_otm_mapping, oracle_din64):
+    from dismember_amd import Engine
+    from dismember_amd.otm_train import OTMTrainer
+    from oracle import otm_oracle as oo
+    rng = np.random.default_rng(77)
+    eng = Engine(0)
+    eng.load_weights_din(fixture_w64.astype(np.float32), 16, 8191)
+    tr = OTMTrainer(eng, leaf_level=12, beam=20)
+    codes, targets = _otm_problem(rng, fixture_otm_mapping, 6)
+    # beamSearchNodes: every level's candidates; ids identical to the f64 oracle for (almost) every user, scores close
+    got = tr.beam_search_nodes(codes)
+    ref = oo.beam_search_nodes(oracle_din64, codes, 10, tr.start_level, 12, 20)
+    assert len(got) == len(ref) == 12 - tr.start_level
+    same = 0
+    for lv in range(len(ref)):
+        for u in range(6):
+            gi = [n for n, _ in got[lv][u]]; ri = [n for n, _ in ref[lv][u]]
+            assert len(gi) == len(ri)
+            if gi == ri:
+                same += 1
+                assert close([s for _, s in got[lv][u]], [s for _, s in ref[lv][u]]).all()
+    assert same >= 0.9 * 6 * len(ref)
+    # pseudo targets: the label bookkeeping is exact when both sides see the same predictions (GPU fp32 scorer)
+    tg = tr.optimal_pseudo_targets(targets, codes)
+    tref = oo.optimal_pseudo_targets(oracle_din64, targets, codes, 10, tr.start_level, 12, pred_fn=lambda n, s: tr._forward(n, s))
+    assert len(tg) == len(tref) == 12 - tr.start_level
+    for lv in range(len(tref)):
+        for u in range(6):
+            assert tg[lv][u].keys() == tref[lv][u].keys()
+            assert all(abs(tg[lv][u][k] - tref[lv][u][k]) < 1e-12 for k in tg[lv][u])
+    # structure: leaf level = the targets with label 1; every level's nodes are ancestors of the targets; labels in [0,1]
+    for u in range(6):
+        assert tg[-1][u] == {t: 1.0 for t in targets[u]}
+        anc = set(targets[u])
+        for lv in range(len(tg) - 2, -1, -1):
+            anc = {(a - 1) >> 1 for a in anc}
+            assert set(tg[lv][u]) == anc and all(0.0 <= v <= 1.0 for v in tg[lv][u].values())
+    # and with its own (f64) predictions the oracle agrees on nearly every label
+    own = oo.optimal_pseudo_targets(oracle_din64, targets, codes, 10, tr.start_level, 12)
+    agree = sum(int(abs(tg[lv][u][k] - own[lv][u].get(k, -9)) < 1e-9) for lv in range(len(tg)) for u in range(6) for k in tg[lv][u])
+    total = sum(len(tg[lv][u]) for lv in range(len(tg)) for u in range(6))
+    assert agree >= 0.97 * total
+    eng.close()
+
+
+def test_otm_train_batch_vs_oracle(fixture_w64, fixture_otm_mapping, oracle):
+    """One LocalOptimizer iteration (O/optim/LocalOptimizer.scala:55-109): per-level losses track the f64 oracle that
+    trains on the same rows (rows and labels taken from the product, so only the numerics are compared)."""
+    from dismember_amd import Engine
+    from dismember_amd.otm_train import OTMTrainer
+    from oracle import otm_oracle as oo
+    rng = np.random.default_rng(78)
+    w = fixture_w64.copy()
+    eng = Engine(0)
+    eng.load_weights_din(w.astype(np.float32), 16, 8191)
+    tr = OTMTrainer(eng, leaf_level=12, beam=20, lr=1e-3)
+    codes, targets = _otm_problem(rng, fixture_otm_mapping, 8)
+    tg = tr.optimal_pseudo_targets(targets, codes)
+    bm = tr.beam_search_nodes(codes)
+    losses = tr.train_batch(codes, targets)
+    assert len(losses) == 12 - tr.start_level and all(np.isfinite(losses))
+    opt = oracle.Adam(w.size, np.float64, lr=1e-3)
+    ref_losses = []
+    for lv in range(len(tg)):
+        c, s, pad, y = oo.level_batch(bm[lv], tg[lv], codes, 10)
+        din = oracle.Din(w, 16, 10, 8191)          # fresh handle: it caches transposed copies of the small matrices
+        loss, g = din.train_grads(c, s, pad, y)
+        opt.step(w, g)
+        ref_losses.append(loss)
+    assert np.abs(np.array(losses) - np.array(ref_losses)).max() < 2e-4
+    wg = eng.train_download("weights")
+    assert np.abs(wg - w).max() < 5e-4        # 8 Adam steps of lr 1e-3; sign-like updates amplify rounding near zero gradients
+    eng.close()
