@@ -52,3 +52,49 @@ def make_users(leaf_ids, n_users, L, rng, zipf_s=1.0, pad_p=0.15):
     npad = rng.binomial(L, pad_p, n_users)
     seq[np.arange(L)[None, :] < npad[:, None]] = 0
     return seq
+
+
+def make_dr_model(num_item, K, D, L, E, rng, scale=0.3, dtype=np.float64):
+    """Deep-Retrieval weights with the reference's shapes (deep-retrieval/.../model/LayerModel.scala:22-39,
+    RerankModel.scala:13-35): layer embedding rows = num_item + K(D-1), layer d Linear((L+d)E -> K),
+    rerank Embedding(num_item, E) + Linear(L*E -> E) + softmaxWeights/softmaxBiases.  `scale` is the std of every
+    matrix (the reference initialises with 0.05; a wider spread gives a peaked, "trained-like" path distribution)."""
+    n = lambda *s: (rng.standard_normal(s) * scale).astype(dtype)
+    return dict(
+        layer_emb=n(num_item + K * (D - 1), E),
+        layer_w=[n(K, (L + d) * E) for d in range(D)],
+        layer_b=[(rng.standard_normal(K) * 0.1).astype(dtype) for _ in range(D)],
+        rerank_emb=n(num_item, E), rerank_w=n(E, L * E), rerank_b=(rng.standard_normal(E) * 0.1).astype(dtype),
+        softmax_w=n(num_item, E), softmax_b=(rng.standard_normal(num_item) * 0.1).astype(dtype))
+
+
+def make_dr_paths(num_item, K, D, J, rng):
+    """J random paths per item (MappingOp.initItemPathMapping, deep-retrieval/.../model/MappingOp.scala:30-43)."""
+    return rng.integers(0, K, size=(num_item, J, D), dtype=np.int32)
+
+
+def dr_path_items(item_paths, collapse=False):
+    """item -> paths [num_item, J, D]  =>  path -> items CSR (distinct paths sorted lexicographically).
+
+    collapse=False keeps every item of a path in ascending id order (the intended inverse map);
+    collapse=True keeps one item per path, the LAST in ascending id order — the shape MappingOp.pathToItems
+    (MappingOp.scala:23-28) really produces, where a Map-typed flatMap overwrites earlier items of the same
+    path (which item survives there depends on HashMap iteration order, so only the shape is reproducible)."""
+    n, J, D = item_paths.shape
+    flat = item_paths.reshape(n * J, D).astype(np.int64)
+    item = np.repeat(np.arange(n, dtype=np.int32), J)
+    order = np.lexsort((item,) + tuple(flat.T[::-1]))
+    flat, item = flat[order], item[order]
+    new = np.ones(len(flat), bool)
+    new[1:] = (flat[1:] != flat[:-1]).any(axis=1)
+    # an item listing the same path twice contributes once (Map key semantics)
+    dup = np.zeros(len(flat), bool)
+    dup[1:] = (~new[1:]) & (item[1:] == item[:-1])
+    flat, item, new = flat[~dup], item[~dup], new[~dup]
+    starts = np.flatnonzero(new)
+    off = np.concatenate([starts, [len(flat)]]).astype(np.int64)
+    paths = flat[starts].astype(np.int32)
+    if collapse:
+        item = item[off[1:] - 1]
+        off = np.arange(len(paths) + 1, dtype=np.int64)
+    return paths, off, item.astype(np.int32)

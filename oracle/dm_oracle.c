@@ -665,3 +665,6 @@ int orc_jtm_rebalance(const int32_t *items, const float *weights, const int32_t 
   (void)items;
   return 0;
 }
+
+/* ------------------------------------------------------------- Deep-Retrieval (row A13) */
+#include "dr_body.inc"

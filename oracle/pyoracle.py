@@ -22,7 +22,7 @@ SCORER_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, i32p, C.c_int, i32p, C.c_int, f64p
 
 
 def build(force=False):
-    src = [os.path.join(_DIR, f) for f in ("dm_oracle.c", "din_body.inc", "Makefile")]
+    src = [os.path.join(_DIR, f) for f in ("dm_oracle.c", "din_body.inc", "dr_body.inc", "Makefile")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _DIR, "-s", "-B"])
     return _SO
@@ -86,6 +86,17 @@ def lib():
         L.orc_otm_beam_nodes.argtypes = [i32p, f64p, C.c_int, C.c_int, C.c_int, i32p]
         L.orc_otm_beam_search.argtypes = [C.c_void_p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, i32p, f64p]
         L.orc_otm_finalize.argtypes = [i32p, f64p, C.c_int, i32p, C.c_int64, C.c_int, i32p, f64p]
+        pp = C.POINTER(f64p)
+        L.orc_dr_create.restype = C.c_void_p
+        L.orc_dr_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, f64p, pp, pp, f64p, f64p, f64p, f64p, f64p]
+        L.orc_dr_destroy.argtypes = [C.c_void_p]
+        L.orc_dr_inference.argtypes = [C.c_void_p, i32p, C.c_int, C.c_int, f64p]
+        L.orc_dr_softmax.argtypes = [f64p, C.c_int, f64p]
+        L.orc_dr_beam_search.argtypes = [C.c_void_p, i32p, C.c_int, i32p, f64p]
+        L.orc_dr_search_candidates.restype = C.c_int64
+        L.orc_dr_search_candidates.argtypes = [i32p, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, i32p, C.c_int64]
+        L.orc_dr_rerank.argtypes = [C.c_void_p, i32p, C.c_int64, i32p, f64p]
+        L.orc_dr_recommend.argtypes = [C.c_void_p, i32p, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, i32p, f64p]
         _lib = L
     return _lib
 
@@ -348,3 +359,93 @@ class Adam:
         pt = f32p if self.dtype == np.float32 else f64p
         fn = lib().orc_adam_step_f32 if self.dtype == np.float32 else lib().orc_adam_step_f64
         fn(_p(w, pt), _p(g, pt), _p(self.s, pt), _p(self.r, pt), w.size, *self.hp, C.byref(self.t))
+
+
+class DeepRetrieval:
+    """fp64 restatement of the Deep-Retrieval serving path (oracle/dr_body.inc).
+
+    weights: dict(layer_emb [(num_item + K(D-1)) x E], layer_w [D] of [K x (L+d)E], layer_b [D] of [K],
+    rerank_emb [num_item x E], rerank_w [E x L*E], rerank_b [E], softmax_w [num_item x E], softmax_b [num_item]).
+    path_items: optional (path_nodes [P x D], item_off [P+1], items) -- sorted here.
+    """
+
+    def __init__(self, weights, E, L, K, D, num_item, path_items=None):
+        L_ = lib()
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.E, self.L, self.K, self.D, self.num_item = E, L, K, D, num_item
+        self._keep = dict(layer_emb=f(weights["layer_emb"]), layer_w=[f(w) for w in weights["layer_w"]],
+                          layer_b=[f(b) for b in weights["layer_b"]], rerank_emb=f(weights["rerank_emb"]),
+                          rerank_w=f(weights["rerank_w"]), rerank_b=f(weights["rerank_b"]),
+                          softmax_w=f(weights["softmax_w"]), softmax_b=f(weights["softmax_b"]))
+        k = self._keep
+        wp = (f64p * D)(*[_p(w, f64p) for w in k["layer_w"]])
+        bp = (f64p * D)(*[_p(b, f64p) for b in k["layer_b"]])
+        self.h = L_.orc_dr_create(E, L, K, D, num_item, _p(k["layer_emb"], f64p), wp, bp, _p(k["rerank_emb"], f64p),
+                                  _p(k["rerank_w"], f64p), _p(k["rerank_b"], f64p), _p(k["softmax_w"], f64p),
+                                  _p(k["softmax_b"], f64p))
+        self.path_items = None
+        if path_items is not None:
+            self.set_path_items(*path_items)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_dr_destroy(self.h)
+            self.h = None
+
+    def set_path_items(self, path_nodes, item_off, items):
+        pn = np.asarray(path_nodes, np.int32).reshape(-1, self.D)
+        off = np.asarray(item_off, np.int64)
+        items = np.asarray(items, np.int32)
+        order = np.lexsort(pn.T[::-1])
+        cnt = (off[1:] - off[:-1])[order]
+        new_off = np.zeros(len(pn) + 1, np.int64)
+        np.cumsum(cnt, out=new_off[1:])
+        new_items = np.concatenate([items[off[o]:off[o + 1]] for o in order]) if len(order) else items[:0]
+        self.path_items = (np.ascontiguousarray(pn[order]), new_off, np.ascontiguousarray(new_items, dtype=np.int32))
+
+    def inference(self, input_ids, rank):
+        x = _i32(input_ids)
+        out = np.empty(self.K, np.float64)
+        lib().orc_dr_inference(self.h, _p(x, i32p), len(x), rank, _p(out, f64p))
+        return out
+
+    def beam_search(self, seq, beam):
+        s = _i32(seq)
+        assert len(s) == self.L
+        paths = np.empty((max(beam, 1), self.D), np.int32)
+        probs = np.empty(max(beam, 1), np.float64)
+        n = lib().orc_dr_beam_search(self.h, _p(s, i32p), beam, _p(paths, i32p), _p(probs, f64p))
+        return paths[:n].copy(), probs[:n].copy()
+
+    def search_candidates(self, paths):
+        pn, off, items = self.path_items
+        paths = np.ascontiguousarray(paths, np.int32)
+        n = lib().orc_dr_search_candidates(_p(paths, i32p), len(paths), self.D, _p(pn, i32p), len(pn), _p(off, i64p),
+                                           _p(items, i32p), None, 0)
+        out = np.empty(max(n, 1), np.int32)
+        lib().orc_dr_search_candidates(_p(paths, i32p), len(paths), self.D, _p(pn, i32p), len(pn), _p(off, i64p),
+                                       _p(items, i32p), _p(out, i32p), n)
+        return out[:n]
+
+    def rerank(self, cands, seq):
+        c = _i32(cands)
+        s = _i32(seq)
+        out = np.empty(max(len(c), 1), np.float64)
+        lib().orc_dr_rerank(self.h, _p(c, i32p), len(c), _p(s, i32p), _p(out, f64p))
+        return out[:len(c)]
+
+    def recommend(self, seq, topk, beam):
+        pn, off, items = self.path_items
+        s = _i32(seq)
+        ids = np.empty(max(topk, 1), np.int32)
+        sc = np.empty(max(topk, 1), np.float64)
+        n = lib().orc_dr_recommend(self.h, _p(s, i32p), topk, beam, _p(pn, i32p), len(pn), _p(off, i64p), _p(items, i32p),
+                                   _p(ids, i32p), _p(sc, f64p))
+        return ids[:n].copy(), sc[:n].copy()
+
+
+def dr_softmax(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib().orc_dr_softmax(_p(x, f64p), len(x), _p(out, f64p))
+    return out

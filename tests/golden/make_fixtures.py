@@ -9,6 +9,7 @@ tests can run on a box that has no /root/reference:
   data/jtm/example_model.bin   -> din_f32.npy    (compact A0 weight vector, E=16, f32)
   data/otm/example_model.bin   -> din_f64.npy    (same layout, f64; OTM)
   data/otm/example_mapping.txt -> otm_mapping.npy (item -> leaf node id)
+  data/dr/example_mapping.bin  -> dr_mapping.npz  (item, id, paths[J][D]; Deep-Retrieval)
 
 Formats decoded here:
   * tree: `[int32 BE len][KVItem]` records, DistTree.loadData
@@ -17,6 +18,10 @@ Formats decoded here:
   * model: Java ObjectOutputStream; the first primitive array of length
     131857 is the compact parameter vector produced by Module.flatten
     (scalann/.../nn/mixin/Module.scala:9-45) in Graph.parameters order.
+
+  * DR mapping: `[int32 BE size][ItemSet]`, MappingOp.loadMapping
+    (deep-retrieval/src/main/scala/com/mass/dr/model/MappingOp.scala:71-95) with the messages of
+    deep-retrieval/src/main/protobuf/item_mapping.proto (packed repeated int32 index).
 
 Only DATA is re-encoded: no reference source travels.
 """
@@ -113,6 +118,36 @@ def read_weights(path, dtype, n=131857):
     return np.frombuffer(b, dtype=dtype, count=n, offset=i + 4).astype(dtype[1:])
 
 
+def read_dr_mapping(path):
+    data = open(path, "rb").read()
+    (n,) = struct.unpack(">i", data[:4])
+    items, ids, paths = [], [], []
+    for f, _, v in pb_fields(data[4:4 + n]):
+        assert f == 1
+        item = idx = 0
+        ps = []
+        for ff, ww, vv in pb_fields(v):
+            if ff == 1:
+                item = to_i32(vv)
+            elif ff == 2:
+                idx = to_i32(vv)
+            elif ff == 3:
+                p = []
+                for f3, w3, v3 in pb_fields(vv):
+                    if w3 == 2:      # packed
+                        i = 0
+                        while i < len(v3):
+                            x, i = varint(v3, i)
+                            p.append(x)
+                    else:
+                        p.append(v3)
+                ps.append(p)
+        items.append(item)
+        ids.append(idx)
+        paths.append(ps)
+    return dict(items=np.array(items, np.int32), ids=np.array(ids, np.int32), paths=np.array(paths, np.int32))
+
+
 def main():
     tree = read_tree(os.path.join(REF, "data/jtm/example_tree.bin"))
     assert tree["max_level"] == 12 and len(tree["leaf_ids"]) == 3706
@@ -125,6 +160,9 @@ def main():
     np.save(os.path.join(OUT, "din_f64.npy"), w64.astype("<f8"))
     m = np.loadtxt(os.path.join(REF, "data/otm/example_mapping.txt"), dtype=np.int64)
     np.save(os.path.join(OUT, "otm_mapping.npy"), m.astype(np.int32))
+    dr = read_dr_mapping(os.path.join(REF, "data/dr/example_mapping.bin"))
+    assert dr["paths"].shape == (3325, 2, 3) and dr["paths"].max() < 100
+    np.savez_compressed(os.path.join(OUT, "dr_mapping.npz"), **dr)
     print("fixtures written to", OUT)
 
 

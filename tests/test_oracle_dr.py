@@ -1,0 +1,134 @@
+"""CPU tests of the Deep-Retrieval oracle (oracle/dr_body.inc): known answers and algebraic invariants.
+The reference holds no golden scores for this path (DeepRetrievalSpec.scala:92-134 is structure only), so the
+restatement is pinned on properties that do not depend on the implementation."""
+import itertools
+
+import numpy as np
+import pytest
+
+from dismember_amd import synth
+from oracle import pyoracle as po
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+
+
+def small_model(K=7, D=3, L=4, E=16, num_item=50, seed=3, scale=0.3):
+    rng = np.random.default_rng(seed)
+    w = synth.make_dr_model(num_item, K, D, L, E, rng, scale=scale)
+    return w, po.DeepRetrieval(w, E, L, K, D, num_item)
+
+
+def np_inference(w, E, ids, d):
+    x = np.concatenate([np.zeros(E) if i == -1 else w["layer_emb"][i] for i in ids])
+    return w["layer_w"][d] @ x + w["layer_b"][d]
+
+
+def test_softmax_known_answers():
+    # D/package.scala:23-28
+    np.testing.assert_allclose(po.dr_softmax([0.0, 0.0]), [0.5, 0.5], rtol=0, atol=0)
+    out = po.dr_softmax([1.0, 2.0, 3.0])
+    e = np.exp(np.array([-2.0, -1.0, 0.0]))
+    np.testing.assert_allclose(out, e / e.sum(), rtol=1e-15)
+    np.testing.assert_allclose(po.dr_softmax([1000.0, 1000.0, -1000.0]), [0.5, 0.5, 0.0], atol=0)   # overflow guard
+
+
+def test_inference_matches_numpy_and_padding():
+    w, m = small_model()
+    ids = [3, -1, 7, 49]
+    np.testing.assert_allclose(m.inference(ids, 0), np_inference(w, 16, ids, 0), rtol=1e-12, atol=1e-13)
+    ids2 = ids + [50 + 2]                       # layer 1: first node id, offset num_item + 0*K
+    np.testing.assert_allclose(m.inference(ids2, 1), np_inference(w, 16, ids2, 1), rtol=1e-12, atol=1e-13)
+
+
+def test_beam_equals_exhaustive_enumeration():
+    """With beam >= K^D nothing is pruned: the result is every path with probability prod_d softmax_d(...),
+    sorted descending; the probabilities sum to 1."""
+    K, D, L, E = 4, 3, 4, 16
+    w, m = small_model(K=K, D=D, L=L, E=E, num_item=30)
+    seq = [1, 5, -1, 29]
+    paths, probs = m.beam_search(seq, K ** D)
+    assert paths.shape == (K ** D, D)
+    assert abs(probs.sum() - 1.0) < 1e-12
+    assert (np.diff(probs) <= 0).all()
+    assert len({tuple(p) for p in paths}) == K ** D
+    ref = {}
+    for path in itertools.product(range(K), repeat=D):
+        ids, pr = list(seq), 1.0
+        for d, node in enumerate(path):
+            lg = np_inference(w, E, ids, d)
+            e = np.exp(lg - lg.max())
+            pr *= (e / e.sum())[node]
+            ids.append(node + 30 + d * K)
+        ref[path] = pr
+    for p, v in zip(paths, probs):
+        assert abs(ref[tuple(p)] - v) < 1e-13
+
+
+def test_beam_prefix_property_and_counts():
+    w, m = small_model(K=9, D=3)
+    seq = [0, 1, 2, 3]
+    p5, v5 = m.beam_search(seq, 5)
+    assert p5.shape == (5, 3) and (np.diff(v5) <= 0).all()
+    # beam=1 is the greedy path
+    p1, v1 = m.beam_search(seq, 1)
+    ids = list(seq)
+    for d in range(3):
+        lg = np_inference(w, 16, ids, d)
+        assert p1[0, d] == int(np.argmax(lg))
+        ids.append(int(p1[0, d]) + 50 + d * 9)
+    # K < beam at layer 0: all K nodes survive layer 0
+    pk, vk = m.beam_search(seq, 20)
+    assert len(pk) == 20
+
+
+def test_stable_ties_keep_path_then_node_order():
+    """All-zero weights: every softmax is uniform, all candidates tie, stable sort keeps (path, node) order."""
+    K, D, L, E, n = 5, 2, 3, 16, 10
+    w = synth.make_dr_model(n, K, D, L, E, np.random.default_rng(0))
+    for k in ("layer_w", "layer_b"):
+        w[k] = [np.zeros_like(a) for a in w[k]]
+    m = po.DeepRetrieval(w, E, L, K, D, n)
+    paths, probs = m.beam_search([1, 2, 3], 7)
+    assert paths.tolist() == [[0, 0], [0, 1], [0, 2], [0, 3], [0, 4], [1, 0], [1, 1]]
+    np.testing.assert_allclose(probs, 1.0 / 25)
+
+
+def test_candidates_rerank_recommend():
+    K, D, L, E, n = 6, 3, 4, 16, 200
+    rng = np.random.default_rng(5)
+    w = synth.make_dr_model(n, K, D, L, E, rng)
+    ip = synth.make_dr_paths(n, K, D, 2, rng)
+    pi = synth.dr_path_items(ip)
+    m = po.DeepRetrieval(w, E, L, K, D, n, path_items=pi)
+    seq = [4, 9, -1, 100]
+    paths, _ = m.beam_search(seq, 10)
+    cands = m.search_candidates(paths)
+    exp = []
+    for p in paths:                      # items of each top path, in path order, ascending id inside a path
+        exp += [i for i in range(n) if any((ip[i, j] == p).all() for j in range(2))]
+    assert cands.tolist() == exp
+    sc = m.rerank(cands, seq)
+    x = np.concatenate([np.zeros(E) if i == -1 else w["rerank_emb"][i] for i in seq])
+    uv = w["rerank_w"] @ x + w["rerank_b"]
+    np.testing.assert_allclose(sc, w["softmax_w"][cands] @ uv + w["softmax_b"][cands], rtol=1e-12, atol=1e-13)
+    ids, scores = m.recommend(seq, 5, 10)
+    order = np.argsort(-sc, kind="stable")[:5]
+    assert ids.tolist() == cands[order].tolist()
+    np.testing.assert_array_equal(scores, sc[order])
+
+
+def test_bundled_mapping_fixture():
+    """data/dr/example_mapping.bin (re-encoded): 3325 items x 2 paths x 3 indices < 100; CSR inversion."""
+    d = np.load(GOLD + "/dr_mapping.npz")
+    assert d["paths"].shape == (3325, 2, 3) and d["paths"].max() < 100
+    assert sorted(d["ids"].tolist()) == list(range(3325))
+    ip = np.empty_like(d["paths"])
+    ip[d["ids"]] = d["paths"]
+    paths, off, items = synth.dr_path_items(ip)
+    assert off[-1] == len(items) and len(paths) == len({tuple(p) for p in ip.reshape(-1, 3)})
+    q = 17
+    lo, hi = off[q], off[q + 1]
+    for it in items[lo:hi]:
+        assert any((ip[it, j] == paths[q]).all() for j in range(2))
+    p1, off1, items1 = synth.dr_path_items(ip, collapse=True)
+    assert (p1 == paths).all() and len(items1) == len(paths) and (items1 == items[off[1:] - 1]).all()
