@@ -24,6 +24,14 @@ class AdamOpts(C.Structure):
                 ("eps", C.c_double)]
 
 
+class DrModel(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("on_device", C.c_int32), ("embed", C.c_int32), ("seq_len", C.c_int32),
+                ("num_node", C.c_int32), ("num_layer", C.c_int32), ("num_item", C.c_int64),
+                ("layer_emb", C.c_void_p), ("layer_w", C.POINTER(C.c_void_p)), ("layer_b", C.POINTER(C.c_void_p)),
+                ("rerank_emb", C.c_void_p), ("rerank_w", C.c_void_p), ("rerank_b", C.c_void_p),
+                ("softmax_w", C.c_void_p), ("softmax_b", C.c_void_p)]
+
+
 class SearchOpts(C.Structure):
     _fields_ = [("beam", C.c_int), ("topk", C.c_int), ("use_mask", C.c_int), ("widen_consumed", C.c_int)]
 
@@ -64,6 +72,13 @@ SIGNATURES = {
                                           i32p, i32p, C.POINTER(C.c_uint32), f32p, C.c_int64, i64p]),
     "dm_train_forward_backward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                 f32p]),
+    "dm_dr_load_model": (C.c_int, [C.c_void_p, C.POINTER(DrModel)]),
+    "dm_dr_load_path_items": (C.c_int, [C.c_void_p, i32p, C.c_int64, i64p, i32p]),
+    "dm_dr_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, i32p, C.POINTER(C.c_double), i32p]),
+    "dm_dr_recommend": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, i32p, C.POINTER(C.c_double), i32p]),
+    "dm_dr_beam_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dm_dr_recommend_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "dm_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dm_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dm_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),

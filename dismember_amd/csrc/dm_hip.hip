@@ -17,10 +17,14 @@
 #include "beam_kernel.hip.inc"
 #include "rows_kernel.hip.inc"
 #include "train_kernel.hip.inc"
+#include "dr_kernel.hip.inc"
 
 #define DM_VERSION 100
 
 // ------------------------------------------------------------------ context
+struct dm_dr_state;
+static void dm_dr_free(dm_dr_state *s);
+
 struct dm_ctx {
   int device = 0;
   int n_cu = 0;
@@ -64,6 +68,8 @@ struct dm_ctx {
   unsigned long long *d_rows = nullptr;
   unsigned long long *d_phase = nullptr;   // 8 debug counters
   int64_t last_rows = 0;
+  // Deep-Retrieval model (dm_dr_load_model)
+  dm_dr_state *dr = nullptr;
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -265,7 +271,7 @@ int dm_destroy(dm_handle_t h) {
   if (!h) return DM_ERR_INVALID;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  free_tree(h); free_weights(h);
+  free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1030,6 +1036,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 
 #include "jtm_host.hip.inc"
 #include "train_host.hip.inc"
+#include "dr_host.hip.inc"
 
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {

@@ -244,6 +244,89 @@ class Engine:
         self._chk(N.lib().dm_train_download(self._h, {"weights": 0, "grad": 1, "s": 2, "r": 3}[what], _p(out, N.f32p), n))
         return out
 
+    # ---- Deep-Retrieval (row A13)
+    def dr_load_model(self, weights, E, L, K, D, num_item, dtype=np.float64):
+        """weights: dict with layer_emb, layer_w [D], layer_b [D] and optionally rerank_emb, rerank_w, rerank_b,
+        softmax_w, softmax_b (numpy arrays; converted to `dtype`, which is also the arithmetic type)."""
+        dt = np.dtype(dtype)
+        f = lambda a: np.ascontiguousarray(a, dtype=dt)
+        keep = dict(layer_emb=f(weights["layer_emb"]), layer_w=[f(w) for w in weights["layer_w"]],
+                    layer_b=[f(b) for b in weights["layer_b"]])
+        assert keep["layer_emb"].size == (num_item + K * (D - 1)) * E
+        for d in range(D):
+            assert keep["layer_w"][d].size == K * (L + d) * E and keep["layer_b"][d].size == K
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        m = N.DrModel()
+        m.dtype = 0 if dt == np.float32 else 1
+        m.on_device = 0
+        m.embed, m.seq_len, m.num_node, m.num_layer, m.num_item = E, L, K, D, num_item
+        m.layer_emb = vp(keep["layer_emb"])
+        wp = (C.c_void_p * D)(*[vp(w) for w in keep["layer_w"]])
+        bp = (C.c_void_p * D)(*[vp(b) for b in keep["layer_b"]])
+        m.layer_w, m.layer_b = wp, bp
+        if weights.get("rerank_emb") is not None:
+            for k in ("rerank_emb", "rerank_w", "rerank_b", "softmax_w", "softmax_b"):
+                keep[k] = f(weights[k])
+                setattr(m, k, vp(keep[k]))
+        self._chk(N.lib().dm_dr_load_model(self._h, C.byref(m)))
+        self.dr_dims = dict(E=E, L=L, K=K, D=D, num_item=num_item, dtype=dt)
+
+    def dr_load_model_dev(self, ptrs, E, L, K, D, num_item, dtype=np.float32):
+        """like dr_load_model but every entry of `ptrs` is a device pointer (c_void_p); layer_w / layer_b are lists."""
+        dt = np.dtype(dtype)
+        m = N.DrModel()
+        m.dtype = 0 if dt == np.float32 else 1
+        m.on_device = 1
+        m.embed, m.seq_len, m.num_node, m.num_layer, m.num_item = E, L, K, D, num_item
+        m.layer_emb = ptrs["layer_emb"]
+        wp = (C.c_void_p * D)(*ptrs["layer_w"])
+        bp = (C.c_void_p * D)(*ptrs["layer_b"])
+        m.layer_w, m.layer_b = wp, bp
+        if ptrs.get("rerank_emb") is not None:
+            for k in ("rerank_emb", "rerank_w", "rerank_b", "softmax_w", "softmax_b"):
+                setattr(m, k, ptrs[k])
+        self._chk(N.lib().dm_dr_load_model(self._h, C.byref(m)))
+        self.dr_dims = dict(E=E, L=L, K=K, D=D, num_item=num_item, dtype=dt)
+
+    def dr_load_path_items(self, path_nodes, item_off, items):
+        pn = _i32(path_nodes).reshape(-1, self.dr_dims["D"])
+        off = np.ascontiguousarray(item_off, dtype=np.int64)
+        it = _i32(items)
+        assert off.size == len(pn) + 1
+        self._chk(N.lib().dm_dr_load_path_items(self._h, _p(pn, N.i32p), len(pn), _p(off, N.i64p), _p(it, N.i32p)))
+
+    def dr_beam_search(self, seq_ids, beam):
+        seq = _i32(seq_ids)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, D = seq.shape[0], self.dr_dims["D"]
+        assert seq.shape[1] == self.dr_dims["L"]
+        paths = np.empty((U, beam, D), np.int32)
+        probs = np.empty((U, beam), np.float64)
+        cnt = np.empty(U, np.int32)
+        self._chk(N.lib().dm_dr_beam_search(self._h, _p(seq, N.i32p), U, int(beam), _p(paths, N.i32p),
+                                            probs.ctypes.data_as(C.POINTER(C.c_double)), _p(cnt, N.i32p)))
+        return paths, probs, cnt
+
+    def dr_recommend(self, seq_ids, beam, topk):
+        seq = _i32(seq_ids)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U = seq.shape[0]
+        assert seq.shape[1] == self.dr_dims["L"]
+        ids = np.empty((U, topk), np.int32)
+        sc = np.empty((U, topk), np.float64)
+        cnt = np.empty(U, np.int32)
+        self._chk(N.lib().dm_dr_recommend(self._h, _p(seq, N.i32p), U, int(beam), int(topk), _p(ids, N.i32p),
+                                          sc.ctypes.data_as(C.POINTER(C.c_double)), _p(cnt, N.i32p)))
+        return ids, sc, cnt
+
+    def dr_beam_search_dev(self, d_seq, U, beam, d_paths, d_probs, d_counts):
+        self._chk(N.lib().dm_dr_beam_search_dev(self._h, d_seq, U, int(beam), d_paths, d_probs, d_counts))
+
+    def dr_recommend_dev(self, d_seq, U, beam, topk, d_ids, d_scores, d_counts):
+        self._chk(N.lib().dm_dr_recommend_dev(self._h, d_seq, U, int(beam), int(topk), d_ids, d_scores, d_counts))
+
     # ---- device-resident path (bench)
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

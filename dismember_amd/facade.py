@@ -76,3 +76,27 @@ class OTM:
             order = sorted(range(len(keep)), key=lambda i: -keep[i][1])
             out.append([(keep[i][0], float(sigmoid(keep[i][1]))) for i in order[:topk]])
         return out[0] if single else out
+
+
+class DeepRetrieval:
+    """DeepRetrieval.recommend(sequence, topk, beamSize, mappings): Seq[(Int, Double)]
+    (deep-retrieval/src/main/scala/com/mass/dr/model/DeepRetrieval.scala:26-46).
+
+    item_id_mapping: dict item -> internal id (MappingOp.itemIdMapping); the path -> items table is loaded into the
+    engine separately (Engine.dr_load_path_items)."""
+
+    def __init__(self, engine: Engine, item_id_mapping):
+        self.engine = engine
+        self.item_id_mapping = dict(item_id_mapping)
+        self.id_item_mapping = {v: k for k, v in self.item_id_mapping.items()}     # MappingOp.scala:16
+
+    def recommend(self, sequence, topk, beam_size):
+        seq = np.asarray(sequence, dtype=np.int64)
+        single = seq.ndim == 1
+        if single:
+            seq = seq[None, :]
+        ids = np.array([[self.item_id_mapping.get(int(i), -1) for i in row] for row in seq], dtype=np.int32)   # :32
+        out_ids, sc, cnt = self.engine.dr_recommend(ids, beam_size, topk)
+        out = [[(self.id_item_mapping[int(i)], float(sigmoid(s))) for i, s in zip(out_ids[u, :cnt[u]], sc[u, :cnt[u]])]
+               for u in range(ids.shape[0])]
+        return out[0] if single else out

@@ -197,6 +197,54 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
                            const int32_t *d_consumed_ids, int32_t *d_out_item_ids, float *d_out_scores,
                            int32_t *d_out_counts);
 
+/* ---- Deep-Retrieval serving ----
+ * D/ = deep-retrieval/src/main/scala/com/mass/dr/.  Item ids here are the INTERNAL ids of
+ * MappingOp.itemIdMapping (D/model/DeepRetrieval.scala:32,45 map in and out; the host facade keeps doing that);
+ * -1 is paddingIdx (D/package.scala:19). */
+typedef struct dm_dr_model {
+  int32_t dtype;        /* DM_F32 | DM_F64: element type of every array below AND the arithmetic type of the path
+                         * (the reference computes in fp64: TensorNumeric.NumericDouble, D/model/LayerModel.scala:7) */
+  int32_t on_device;    /* 0: host arrays; 1: device arrays (copied device-to-device, the caller keeps ownership) */
+  int32_t embed;        /* embedSize, multiple of 16 */
+  int32_t seq_len;      /* seqLen */
+  int32_t num_node;     /* K = numNode */
+  int32_t num_layer;    /* D = numLayer, 2..4 (D/model/LayerModel.scala:12 requires >= 2) */
+  int64_t num_item;
+  const void *layer_emb;        /* LayerModel.embedParams   [(num_item + K(D-1)) x E]      D/model/LayerModel.scala:15,24 */
+  const void *const *layer_w;   /* [D] LayerModel.linearParams(d).head  [K x (seq_len+d)E] D/model/LayerModel.scala:16-18,31-36 */
+  const void *const *layer_b;   /* [D] LayerModel.linearParams(d).last  [K] */
+  const void *rerank_emb;       /* RerankModel.embedParams  [num_item x E]                 D/model/RerankModel.scala:13 */
+  const void *rerank_w;         /* RerankModel.linearParams.head [E x seq_len*E]           D/model/RerankModel.scala:14,32-34 */
+  const void *rerank_b;         /* RerankModel.linearParams.last [E] */
+  const void *softmax_w;        /* RerankModel.softmaxWeights [num_item x E]               D/model/RerankModel.scala:15 */
+  const void *softmax_b;        /* RerankModel.softmaxBiases  [num_item]                   D/model/RerankModel.scala:16 */
+                                /* the five rerank arrays may all be NULL: beam search only */
+} dm_dr_model;
+/* replaces the state DeepRetrieval.loadModel / LayerModel / RerankModel hold (D/model/DeepRetrieval.scala:90-106);
+ * also precomputes the per-(layer, position) node tables, see DESIGN.md */
+int dm_dr_load_model(dm_handle_t h, const dm_dr_model *model);
+/* MappingOp.pathItemMapping (D/model/MappingOp.scala:14-28) as a CSR over DISTINCT paths: path_nodes [n_paths x D],
+ * items of path i = items[item_off[i] .. item_off[i+1]) in the order searchCandidate should yield them
+ * (D/model/CandidateSearcher.scala:14-19).  Any path order; duplicate paths -> DM_ERR_INVALID. */
+int dm_dr_load_path_items(dm_handle_t h, const int32_t *path_nodes, int64_t n_paths, const int64_t *item_off,
+                          const int32_t *items);
+/* CandidateSearcher.beamSearch (D/model/CandidateSearcher.scala:22-60) for U users: seq_ids [U x seq_len] internal ids;
+ * out_paths [U x beam x D] nodes in layer order (-1 beyond the count), out_probs [U x beam] path probabilities in
+ * descending order (ties: earlier parent path, then lower node — the stable sortBy of :49-51), out_counts [U]. */
+int dm_dr_beam_search(dm_handle_t h, const int32_t *seq_ids, int64_t U, int beam, int32_t *out_paths, double *out_probs,
+                      int32_t *out_counts);
+/* DeepRetrieval.recommend (D/model/DeepRetrieval.scala:26-46) on internal ids: searchCandidate + RerankModel.inference
+ * (D/model/RerankModel.scala:43-52) + stable descending sort + take(topk).  out_ids [U x topk] internal item ids
+ * (-1 beyond the count; an item reachable through several top paths appears once per path, as in the reference),
+ * out_scores [U x topk] rerank LOGITS (the reference applies sigmoid in double afterwards, :45). */
+int dm_dr_recommend(dm_handle_t h, const int32_t *seq_ids, int64_t U, int beam, int topk, int32_t *out_ids,
+                    double *out_scores, int32_t *out_counts);
+/* device-resident variants (asynchronous on the handle's stream; ids are NOT range-checked) */
+int dm_dr_beam_search_dev(dm_handle_t h, const int32_t *d_seq_ids, int64_t U, int beam, int32_t *d_out_paths,
+                          double *d_out_probs, int32_t *d_out_counts);
+int dm_dr_recommend_dev(dm_handle_t h, const int32_t *d_seq_ids, int64_t U, int beam, int topk, int32_t *d_out_ids,
+                        double *d_out_scores, int32_t *d_out_counts);
+
 /* ---- synthetic-data helpers (bench / tests only; nothing in the reference corresponds) ---- */
 /* fill d_ptr[0..n) (float, device) with N(mean, std): counter-based splitmix64 + Box-Muller, reproducible per (seed, index) */
 int dm_fill_normal(dm_handle_t h, float *d_ptr, int64_t n, float mean, float std, uint64_t seed);
