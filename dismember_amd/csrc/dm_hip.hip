@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -244,8 +245,8 @@ int dm_create(int device_id, dm_handle_t *out) {
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipGetDeviceProperties failed"); }
   h->n_cu = prop.multiProcessorCount;
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipStreamCreate failed"); }
-  if (hipMalloc((void **)&h->d_rows, 16) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
-  (void)hipMemset(h->d_rows, 0, 16);
+  if (hipMalloc((void **)&h->d_rows, 64) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
+  (void)hipMemset(h->d_rows, 0, 64);
   if (hipMalloc((void **)&h->d_phase, 128) == hipSuccess) (void)hipMemset(h->d_phase, 0, 128);
   *out = h;
   return DM_OK;
@@ -1089,6 +1090,14 @@ extern "C" int dm_debug_phase_cycles(dm_handle_t h, unsigned long long *out8) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out8, h->d_phase, 128, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemset(h->d_phase, 0, 128));
+  return DM_OK;
+}
+// debug (not part of the public header): Deep-Retrieval layers that fell back to the exact radix-select path
+extern "C" int dm_debug_dr_slow_layers(dm_handle_t h, unsigned long long *out, int reset) {
+  if (!h || !out) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_rows + 2, 8, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(h, hipMemset(h->d_rows + 2, 0, 8));
   return DM_OK;
 }
 int dm_last_scored_rows(dm_handle_t h, int64_t *rows) {

@@ -288,6 +288,28 @@ class Engine:
         self._chk(N.lib().dm_dr_load_model(self._h, C.byref(m)))
         self.dr_dims = dict(E=E, L=L, K=K, D=D, num_item=num_item, dtype=dt)
 
+    def dr_load_model_synthetic(self, E, L, K, D, num_item, seed, scale=0.05, rerank=True):
+        """Random-init Deep-Retrieval model generated ON THE DEVICE in f32 (N(0, scale) matrices, zero biases —
+        the reference's init, RerankModel.scala:15-16) and loaded without a host copy (bench only)."""
+        fill = lambda n, sd, std: self._fill_new(n, sd, std)
+        ptrs = dict(layer_emb=fill((num_item + K * (D - 1)) * E, seed + 1, scale),
+                    layer_w=[fill(K * (L + d) * E, seed + 10 + d, scale) for d in range(D)],
+                    layer_b=[fill(K, seed + 20 + d, 0.0) for d in range(D)])
+        if rerank:
+            ptrs.update(rerank_emb=fill(num_item * E, seed + 2, scale), rerank_w=fill(E * L * E, seed + 3, scale),
+                        rerank_b=fill(E, seed + 4, 0.0), softmax_w=fill(num_item * E, seed + 5, scale),
+                        softmax_b=fill(num_item, seed + 6, 0.0))
+        self.dr_load_model_dev(ptrs, E, L, K, D, num_item, dtype=np.float32)
+        self.synchronize()
+        for k, v in ptrs.items():
+            for q in (v if isinstance(v, list) else [v]):
+                self.dev_free(q)
+
+    def _fill_new(self, n, seed, std):
+        d = self.dev_alloc(int(n) * 4)
+        self._chk(N.lib().dm_fill_normal(self._h, d, int(n), 0.0, float(std), int(seed)))
+        return d
+
     def dr_load_path_items(self, path_nodes, item_off, items):
         pn = _i32(path_nodes).reshape(-1, self.dr_dims["D"])
         off = np.ascontiguousarray(item_off, dtype=np.int64)

@@ -164,9 +164,9 @@ def test_recommend_bundled_mapping_and_facade():
     model = DeepRetrieval(eng, item_id)
     query = [1, 2, 3, 4, 5, 6, 7, 89, 2628, 1681]
     # random weights know nothing about the 6 627 occupied paths (of 10^6): a wide beam is needed to hit some
-    recs = model.recommend(query, 10, 2000)
+    recs = model.recommend(query, 10, 1000)
     seq_ids = [item_id.get(i, -1) for i in query]
-    oi, osc = orc.recommend(seq_ids, 10, 2000)
+    oi, osc = orc.recommend(seq_ids, 10, 1000)
     assert len(recs) >= 3                               # DeepRetrievalSpec.scala:112
     assert [r[0] for r in recs] == [id_item[int(i)] for i in oi]
     np.testing.assert_allclose([r[1] for r in recs], 1.0 / (1.0 + np.exp(-osc)), rtol=1e-9)

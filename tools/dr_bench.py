@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Deep-Retrieval serving micro-benchmark (BASELINE config 5 shape): D=3, K=1000, beam=50, E=128, L=10.
+Times dm_dr_beam_search_dev (and dm_dr_recommend_dev) with inputs resident in HBM; prints per-kernel event time."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dismember_amd import Engine, synth   # noqa: E402
+
+
+def fast_path_items(item_paths, K):
+    n, J, D = item_paths.shape
+    code = np.zeros(n * J, np.int64)
+    for d in range(D):
+        code = code * K + item_paths[:, :, d].reshape(-1)
+    item = np.repeat(np.arange(n, dtype=np.int32), J)
+    order = np.argsort(code, kind="stable")
+    code, item = code[order], item[order]
+    new = np.ones(len(code), bool)
+    new[1:] = code[1:] != code[:-1]
+    dup = np.zeros(len(code), bool)
+    dup[1:] = (~new[1:]) & (item[1:] == item[:-1])
+    code, item, new = code[~dup], item[~dup], new[~dup]
+    starts = np.flatnonzero(new)
+    off = np.concatenate([starts, [len(code)]]).astype(np.int64)
+    c = code[starts]
+    paths = np.empty((len(c), D), np.int32)
+    for d in range(D - 1, -1, -1):
+        paths[:, d] = c % K
+        c //= K
+    return paths, off, item
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, default=10_000_000)
+    ap.add_argument("--users", type=int, default=16384)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--K", type=int, default=1000)
+    ap.add_argument("--D", type=int, default=3)
+    ap.add_argument("--beam", type=int, default=50)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--embed", type=int, default=128)
+    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--rerank", type=int, default=1)
+    a = ap.parse_args()
+    E, L, K, D, U = a.embed, a.seq_len, a.K, a.D, a.users
+    rng = np.random.default_rng(synth.SEED)
+    eng = Engine(0)
+    t0 = time.perf_counter()
+    eng.dr_load_model_synthetic(E, L, K, D, a.items, synth.SEED, scale=0.05, rerank=bool(a.rerank))
+    t_model = time.perf_counter() - t0
+    seqs = rng.integers(0, a.items, size=(U, L)).astype(np.int32)
+    seqs[rng.random((U, L)) < 0.15] = -1
+    d_seq = eng.dev_alloc(U * L * 4); eng.h2d(d_seq, seqs)
+    d_paths = eng.dev_alloc(U * a.beam * D * 4); d_probs = eng.dev_alloc(U * a.beam * 8); d_cnt = eng.dev_alloc(U * 4)
+    out = {"model_load_s": t_model}
+    import ctypes as C
+    from dismember_amd import _native as N
+    eng.dr_beam_search_dev(d_seq, U, a.beam, d_paths, d_probs, d_cnt)
+    eng.synchronize(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.dr_beam_search_dev(d_seq, U, a.beam, d_paths, d_probs, d_cnt)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    nl, ms = eng.timing_get()
+    out["beam_search"] = {"users_per_s": U * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_ms_per_step": ms / a.steps,
+                          "launches_per_step": nl / a.steps}
+    slow = C.c_ulonglong(0)
+    N.lib().dm_debug_dr_slow_layers.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    N.lib().dm_debug_dr_slow_layers(eng._h, C.byref(slow), 1)
+    out["beam_search"]["exact_path_layers_per_user"] = slow.value / float(U * (a.steps + 1))
+    if a.rerank:
+        t0 = time.perf_counter()
+        pi = fast_path_items(synth.make_dr_paths(a.items, K, D, 2, rng), K)
+        eng.dr_load_path_items(*pi)
+        out["path_table_s"] = time.perf_counter() - t0
+        out["paths"] = int(len(pi[0]))
+        d_ids = eng.dev_alloc(U * a.topk * 4); d_sc = eng.dev_alloc(U * a.topk * 8)
+        eng.dr_recommend_dev(d_seq, U, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        eng.synchronize(); eng.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.dr_recommend_dev(d_seq, U, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        nl, ms = eng.timing_get()
+        cnt = np.empty(U, np.int32); eng.d2h(cnt, d_cnt)
+        out["recommend"] = {"users_per_s": U * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_ms_per_step": ms / a.steps,
+                            "mean_recs": float(cnt.mean())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
