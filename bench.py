@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--rho", type=float, default=0.95, help="parent-child correlation of the synthetic node embeddings")
     ap.add_argument("--train", type=int, default=1, help="also time a training step (0 = skip)")
     ap.add_argument("--big", type=int, default=1, help="also time the 10M-item depth-24 tree (BASELINE metric's catalogue size); 0 = skip")
+    ap.add_argument("--dr", type=int, default=1, help="also time Deep-Retrieval serving (config 5: D=3, K=1000, beam=50, 10M items); 0 = skip")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
     return ap.parse_args()
 
@@ -268,7 +269,62 @@ def main():
             big["recall_at_%d_vs_bruteforce" % a.topk] = float(np.mean(
                 [len(set(ids2[u, :cnt2[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]))
             big["recall_users"] = nr
+    # ---- extra: Deep-Retrieval serving, BASELINE config 5 (row A13): D=3, K=1000, beam=50, 10M items ----
+    dr = None
+    if a.dr and (a.items, a.depth) == (1_000_000, 20):
+        eng.close()
+        eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+        Kd, Dd, beam_d, topk_d, items_d, Ud = 1000, 3, 50, 10, 10_000_000, 16384
+        eng.dr_load_model_synthetic(E, L, Kd, Dd, items_d, synth.SEED, scale=0.05, rerank=True)
+        drng = np.random.default_rng(synth.SEED + 303 + rank)
+        dseq = drng.integers(0, items_d, size=(Ud, L)).astype(np.int32)
+        dseq[drng.random((Ud, L)) < 0.15] = -1
+        eng.dr_load_path_items(*synth.dr_path_items_fast(synth.make_dr_paths(items_d, Kd, Dd, 2, np.random.default_rng(synth.SEED)), Kd))
+        q_seq = eng.dev_alloc(Ud * L * 4); eng.h2d(q_seq, dseq)
+        q_paths = eng.dev_alloc(Ud * beam_d * Dd * 4); q_probs = eng.dev_alloc(Ud * beam_d * 8); q_cnt = eng.dev_alloc(Ud * 4)
+        q_ids = eng.dev_alloc(Ud * topk_d * 4); q_sc = eng.dev_alloc(Ud * topk_d * 8)
+        nsd = max(2, a.steps // 2)
+        eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
+        sync(); eng.timing_reset(); barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(nsd):
+            eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
+        sync(); barrier()
+        dtb = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        _, kms_b = eng.timing_get()
+        eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(nsd):
+            eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
+        sync(); barrier()
+        dtr = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        # per user: 3 history GEMM rows of K x L*E (the only matrix work left) + (1 + 50 + 50) table-row sums of K
+        table_bytes = (beam_d * 1 + beam_d * 2) * Kd * 4
+        dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x 2 paths, %d-d, f32 (reference computes in f64)"
+                          % (Dd, Kd, beam_d, items_d, E),
+              "beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
+              "beam_search_kernel_ms_per_step": kms_b / nsd,
+              "recommend_users_per_s": world * Ud * nsd / dtr, "users_per_step": Ud, "steps": nsd,
+              "gemm_flop_per_user": 2 * Dd * Kd * L * E, "table_row_bytes_per_user": table_bytes,
+              "reference_formulation_flop_per_user": 2 * Kd * E * (L + beam_d * (L + 1) + beam_d * (L + 2))}
+        if rank == 0 and a.cpu_users != 0:
+            from oracle import pyoracle as po
+            small_items = 20000
+            wsm = synth.make_dr_model(small_items, Kd, Dd, L, E, np.random.default_rng(1), scale=0.05)
+            orc = po.DeepRetrieval(wsm, E, L, Kd, Dd, small_items)
+            cs = np.random.default_rng(2).integers(0, small_items, size=(24, L)).astype(np.int32)
+            orc.beam_search(cs[0], beam_d)
+            t0 = time.perf_counter()
+            for r_ in cs:
+                orc.beam_search(r_, beam_d)
+            dtc = time.perf_counter() - t0
+            dr["cpu_baseline"] = {"value": len(cs) / dtc, "unit": "users/s", "cores": 1, "kind": "port",
+                                  "sample": "%d users, fp64 oracle beam search (same D, K, beam, E, L; %d-item catalogue: the work per "
+                                            "user does not depend on the catalogue size), 1 thread" % (len(cs), small_items)}
     if rank == 0:
+        if dr is not None:
+            res_main["extra_deep_retrieval"] = dr
         if big is not None:
             res_main["extra_10m_item_tree"] = big
         if train is not None:

@@ -98,3 +98,27 @@ def dr_path_items(item_paths, collapse=False):
         item = item[off[1:] - 1]
         off = np.arange(len(paths) + 1, dtype=np.int64)
     return paths, off, item.astype(np.int32)
+
+
+def dr_path_items_fast(item_paths, K):
+    """dr_path_items(collapse=False) for large catalogues: path codes + one stable argsort instead of a lexsort."""
+    n, J, D = item_paths.shape
+    code = np.zeros(n * J, np.int64)
+    for d in range(D):
+        code = code * K + item_paths[:, :, d].reshape(-1)
+    item = np.repeat(np.arange(n, dtype=np.int32), J)
+    order = np.argsort(code, kind="stable")
+    code, item = code[order], item[order]
+    new = np.ones(len(code), bool)
+    new[1:] = code[1:] != code[:-1]
+    dup = np.zeros(len(code), bool)
+    dup[1:] = (~new[1:]) & (item[1:] == item[:-1])
+    code, item, new = code[~dup], item[~dup], new[~dup]
+    starts = np.flatnonzero(new)
+    off = np.concatenate([starts, [len(code)]]).astype(np.int64)
+    c = code[starts]
+    paths = np.empty((len(c), D), np.int32)
+    for d in range(D - 1, -1, -1):
+        paths[:, d] = c % K
+        c = c // K
+    return paths, off, item

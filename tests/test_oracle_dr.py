@@ -130,5 +130,7 @@ def test_bundled_mapping_fixture():
     lo, hi = off[q], off[q + 1]
     for it in items[lo:hi]:
         assert any((ip[it, j] == paths[q]).all() for j in range(2))
+    pf, offf, itemsf = synth.dr_path_items_fast(ip, 100)
+    assert (pf == paths).all() and (offf == off).all() and (itemsf == items).all()
     p1, off1, items1 = synth.dr_path_items(ip, collapse=True)
     assert (p1 == paths).all() and len(items1) == len(paths) and (items1 == items[off[1:] - 1]).all()

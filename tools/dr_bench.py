@@ -13,29 +13,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dismember_amd import Engine, synth   # noqa: E402
 
 
-def fast_path_items(item_paths, K):
-    n, J, D = item_paths.shape
-    code = np.zeros(n * J, np.int64)
-    for d in range(D):
-        code = code * K + item_paths[:, :, d].reshape(-1)
-    item = np.repeat(np.arange(n, dtype=np.int32), J)
-    order = np.argsort(code, kind="stable")
-    code, item = code[order], item[order]
-    new = np.ones(len(code), bool)
-    new[1:] = code[1:] != code[:-1]
-    dup = np.zeros(len(code), bool)
-    dup[1:] = (~new[1:]) & (item[1:] == item[:-1])
-    code, item, new = code[~dup], item[~dup], new[~dup]
-    starts = np.flatnonzero(new)
-    off = np.concatenate([starts, [len(code)]]).astype(np.int64)
-    c = code[starts]
-    paths = np.empty((len(c), D), np.int32)
-    for d in range(D - 1, -1, -1):
-        paths[:, d] = c % K
-        c //= K
-    return paths, off, item
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--items", type=int, default=10_000_000)
@@ -78,7 +55,7 @@ def main():
     out["beam_search"]["exact_path_layers_per_user"] = slow.value / float(U * (a.steps + 1))
     if a.rerank:
         t0 = time.perf_counter()
-        pi = fast_path_items(synth.make_dr_paths(a.items, K, D, 2, rng), K)
+        pi = synth.dr_path_items_fast(synth.make_dr_paths(a.items, K, D, 2, rng), K)
         eng.dr_load_path_items(*pi)
         out["path_table_s"] = time.perf_counter() - t0
         out["paths"] = int(len(pi[0]))
