@@ -153,7 +153,7 @@ def main():
         kq = (L + 3) // 4
         flops_own = 2 * (E * E + 2 * L * E + E)                     # this formulation, per scored row
         flops_ref = 2 * (2 * L * E + 3 * E * E + E)                 # SURVEY.md §8d, reference formulation
-        mfma_issued = ((E // 16) * 4 + kq * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0
+        mfma_issued = ((E // 16) * 4 + 4 * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0   # S^T + P x G (4 k-steps) + main chain
         ach = rows * flops_own / (avg_ms * 1e-3) / 1e12
         res = {
             "metric": "beam-search users/sec (TDM serve, 1M-item depth-20 tree, 128-d, beam 200)",
@@ -181,11 +181,11 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01b_summary.json")))
             pw = prof["bench_line_under_profiler"]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                res["roofline"]["traffic_source"] = ("profiles/r01b_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                      "(separate passes), bytes per launch, FETCH x2 gfx950 correction")
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         except Exception:

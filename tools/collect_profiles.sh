@@ -6,7 +6,7 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 4 --warmup 1 --cpu-users 0 --recall-users 0"
+ARGS="--steps 4 --warmup 1 --cpu-users 0 --recall-users 0 --big 0 --train 0 --dr 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o p -- python bench.py $ARGS > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python bench.py $ARGS > $OUT/bench_pmc2.log 2>&1

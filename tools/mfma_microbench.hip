@@ -21,6 +21,9 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters) {
 #pragma unroll
   for (int j = 0; j < 8; j++) q[j] = (f32x4){1.f + lane, 2.f + j, 3.f, 4.f};
   float v = (float)lane;
+  float vv[8];
+#pragma unroll
+  for (int n = 0; n < 8; n++) vv[n] = (float)(lane + n);
   for (int it = 0; it < iters; it++) {
     if (MODE == 0) {
 #pragma unroll
@@ -45,6 +48,9 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters) {
           for (int n = 0; n < 8; n++) {
             acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[jc][t], wb[jc & 1][n][t], acc[n], 0, 0, 0);
             if (MODE == 2) { v = fmaf(v, 1.0001f, 0.5f); v = fmaf(v, 0.9999f, 0.25f); v = fmaf(v, 1.0002f, 0.125f); }
+            if (MODE == 4) { vv[n] = fmaf(vv[n], 1.0001f, 0.5f); vv[(n + 3) & 7] = fmaf(vv[(n + 3) & 7], 0.9999f, 0.25f); vv[(n + 5) & 7] = fmaf(vv[(n + 5) & 7], 1.0002f, 0.125f); }
+            if (MODE == 5) { vv[n] = fmaf(vv[n], 1.0001f, 0.5f); }
+            if (MODE == 6 && (n & 3) == 0) { vv[n] = fmaf(vv[n], 1.0001f, 0.5f); }
           }
         }
       }
@@ -55,6 +61,8 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters) {
     }
   }
   float s = v;
+#pragma unroll
+  for (int n = 0; n < 8; n++) s += vv[n];
 #pragma unroll
   for (int n = 0; n < 8; n++) s += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
   out[blockIdx.x * 512 + threadIdx.x] = s;
@@ -79,5 +87,8 @@ int main() {
   run<1>("mfma + ds_read_b128 per 4", d, 2000);
   run<2>("mfma + lds + 3 VALU per mfma", d, 2000);
   run<3>("mfma + lds + 300-VALU block", d, 2000);
+  run<4>("mfma + lds + 3 indep VALU per mfma", d, 2000);
+  run<5>("mfma + lds + 1 indep VALU per mfma", d, 2000);
+  run<6>("mfma + lds + 1 VALU per 4 mfma", d, 2000);
   return 0;
 }

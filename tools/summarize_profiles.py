@@ -15,7 +15,7 @@ out = {"tag": tag}
 for f in glob.glob(src + "/trace/*kernel_stats.csv"):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
     for r in csv.DictReader(open(f)):
-        if "beam" in r["Name"]:
+        if "dm_beam_kernel" in r["Name"]:
             out["kernel_trace"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                    "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
 pmc = {}
@@ -24,7 +24,7 @@ for d in sorted(glob.glob(src + "/pmc_*")):
         acc = collections.defaultdict(float)
         n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if "beam" in r["Kernel_Name"]:
+            if "dm_beam_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 n[r["Counter_Name"]] += 1
         for k in acc:
