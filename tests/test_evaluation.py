@@ -1,0 +1,85 @@
+"""Evaluator + metrics: known answers for the oracle restatement and the host mirror (CPU), and
+the device evaluator against the oracle evaluator on the reference's bundled tree + model (GPU)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from dismember_amd import evaluation as ev
+from oracle import eval_oracle as eo
+
+
+def test_metrics_known_answers():
+    # hits at positions 0 and 2 of 4 returned, 3 labels: precision 2/4, recall 2/3,
+    # dcg = 1 + log2/log4 = 1.5, idcg = 1 + log2/log3
+    rec, lab = [7, 1, 9, 4], [9, 7, 100]
+    exp = (0.5, 2 / 3.0, 1.5 / (1 + math.log(2) / math.log(3)))
+    for f in (eo.compute_metrics, ev.compute_metrics):
+        got = f(rec, lab)
+        assert got == pytest.approx(exp, rel=1e-15)
+        assert f([1, 2, 3], [4]) == (0.0, 0.0, 0.0)
+        assert f([5], [5]) == (1.0, 1.0, 1.0)
+        # precision is over the items actually returned (k = recItems.length), not topk
+        assert f([5, 6], [6, 5, 1, 2])[0] == 1.0
+    assert ev.compute_metrics([], [1]) == (0.0, 0.0, 0.0)
+
+
+def test_metrics_host_mirror_equals_restatement():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        k = int(rng.integers(1, 30))
+        rec = rng.permutation(60)[:k]
+        lab = rng.permutation(60)[:int(rng.integers(1, 12))]
+        assert ev.compute_metrics(rec, lab) == pytest.approx(eo.compute_metrics(rec, lab), rel=1e-14, abs=0)
+
+
+def test_bce_and_evalresult():
+    x = np.array([0.0, 2.0, -3.0], np.float32)
+    z = np.array([1.0, 0.0, 1.0], np.float32)
+    exp = (math.log(2) + (2 + math.log1p(math.exp(-2))) + math.log1p(math.exp(-3)) - (0 * 1 + 2 * 0 + -3 * 1)) / 3
+    assert eo.bce_with_logits(x, z) == pytest.approx(exp, rel=1e-6)
+    assert ev.bce_with_logits(x, z) == pytest.approx(exp, rel=1e-6)
+    r = ev.EvalResult(loss=2.0, count=2)
+    r.add_metrics((0.5, 0.25, 1.0))
+    r = r + ev.EvalResult(loss=1.0, precision=0.5, recall=0.75, ndcg=0.0, count=2)
+    assert str(r) == "{eval loss: 0.7500, precision: 0.250000, recall: 0.250000, ndcg: 0.250000}"
+    assert str(r) == str(eo.EvalResult(3.0, 1.0, 1.0, 1.0, 4))
+
+
+@pytest.mark.gpu
+def test_evaluate_vs_oracle(fixture_tree, fixture_w32, oracle, oracle_tree):
+    from dismember_amd import Engine
+    t = fixture_tree
+    E, L, depth = 16, 10, int(t["max_level"])
+    ni = (1 << (depth + 1)) - 1
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], depth)
+    eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(fixture_w32, E, ni)
+    din = oracle.Din(fixture_w32, E, L, ni)
+    rng = np.random.default_rng(11)
+    N = 40
+    items = t["leaf_ids"]
+    seqs = rng.choice(items, size=(N, L)).astype(np.int32)
+    seqs[rng.random((N, L)) < 0.2] = 0
+    labels = [rng.choice(items, size=int(rng.integers(1, 8)), replace=False).astype(np.int32) for _ in range(N)]
+    users = rng.integers(0, 12, size=N)
+    consumed = {u: rng.choice(items, size=int(rng.integers(5, 60)), replace=False).astype(np.int32) for u in range(12)}
+    neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], np.int32)
+    res, batches = ev.evaluate(eng, seqs, labels, users, consumed, neg, topk=10, candidate_num=40, batch_size=900,
+                               return_batches=True)
+    ores = eo.evaluate(oracle_tree, din, seqs, labels, users, consumed, batches, topk=10, candidate_num=40)
+    assert res.count == ores.count == N
+    assert res.loss == pytest.approx(ores.loss, rel=1e-4)
+    # metrics are sums of per-user ratios of small integers: equal unless a near-tie flips an id list
+    assert res.precision == pytest.approx(ores.precision, abs=0.11)
+    assert res.recall == pytest.approx(ores.recall, abs=0.5)
+    assert res.ndcg == pytest.approx(ores.ndcg, abs=0.5)
+    # per-user lists: identical for nearly all users
+    ids, _, cnt = eng.tdm_beam_search(seqs, 40, 10, consumed=[consumed[int(u)] for u in users], widen_consumed=True)
+    same = sum(int(ids[i, :cnt[i]].tolist() == oracle_tree.recommend_items(din, seqs[i], 10, 40, consumed=consumed[int(users[i])]).tolist())
+               for i in range(N))
+    assert same >= N - 2
+    if same == N:
+        assert (res.precision, res.recall, res.ndcg) == pytest.approx((ores.precision, ores.recall, ores.ndcg), rel=1e-12)
