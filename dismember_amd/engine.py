@@ -52,6 +52,14 @@ class Engine:
         self._chk(N.lib().dm_load_tree_tdm(self._h, _p(codes, N.i32p), _p(node_ids, N.i32p), _p(is_leaf, N.u8p),
                                            codes.size, int(max_level)))
 
+    def load_tree_file(self, path):
+        """DistTree.loadData (tdm/.../tree/DistTree.scala:40-87): a reference tree file -> device index."""
+        from . import tree_io
+        t = tree_io.read_tree_file(path)
+        self.load_tree(t["codes"], t["ids"], t["is_leaf"], t["max_level"])
+        self.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+        return t
+
     def load_id_maps(self, leaf_item_ids, leaf_codes):
         a, b = _i32(leaf_item_ids), _i32(leaf_codes)
         self._chk(N.lib().dm_load_id_maps(self._h, _p(a, N.i32p), _p(b, N.i32p), a.size))

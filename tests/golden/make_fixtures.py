@@ -5,10 +5,12 @@ Re-encodes the reference's bundled *data files* (BSD-3-Clause, see the
 reference LICENSE) as plain little-endian numpy arrays so that the parity
 tests can run on a box that has no /root/reference:
 
-  data/jtm/example_tree.bin    -> tdm_tree.npz   (protobuf-KV tree, max_level 12)
+  data/jtm/example_tree.bin    -> tdm_tree.npz   (protobuf-KV tree, max_level 12; + the target statistics it was
+                                  built from, and tdm_tree_file.json = size and sha256 of the original file)
   data/jtm/example_model.bin   -> din_f32.npy    (compact A0 weight vector, E=16, f32)
   data/otm/example_model.bin   -> din_f64.npy    (same layout, f64; OTM)
   data/otm/example_mapping.txt -> otm_mapping.npy (item -> leaf node id)
+  data/example_data.csv        -> example_data.npz (interactions in time order + distinct items with category)
   data/dr/example_mapping.bin  -> dr_mapping.npz  (item, id, paths[J][D]; Deep-Retrieval)
 
 Formats decoded here:
@@ -111,6 +113,43 @@ def read_tree(path):
                 max_level=np.int32(max_level))
 
 
+def derive_stat(tree):
+    """Item target counts (`stat`) that TreeBuilder.build was given, recovered from the node probabilities it wrote:
+    a leaf's probability is its count (1.0 when the item had none), an ancestor's the sum over its leaves (1.0 when
+    that sum is empty) — T/tree/TreeBuilder.scala:35-38,48-52,66-67,148-162.  Where 1.0 is ambiguous the parent's
+    total decides; remaining ties produce identical files."""
+    sys.setrecursionlimit(10000)
+    prob = dict(zip(tree["codes"].tolist(), tree["probs"].tolist()))
+    idof = dict(zip(tree["codes"].tolist(), tree["ids"].tolist()))
+    leaf = dict(zip(tree["codes"].tolist(), tree["is_leaf"].tolist()))
+    stat = {}
+
+    def assign(node, total):
+        if leaf[node]:
+            if total > 0:
+                stat[idof[node]] = int(total)
+            return
+        kids = [k for k in (2 * node + 1, 2 * node + 2) if k in prob]
+        if len(kids) == 1:
+            return assign(kids[0], total)
+        a, b = kids
+        amb = [prob[k] == 1.0 for k in kids]
+        if not amb[0] and not amb[1]:
+            ta, tb = prob[a], prob[b]
+        elif amb[0] and not amb[1]:
+            tb = prob[b]; ta = total - tb
+        elif amb[1] and not amb[0]:
+            ta = prob[a]; tb = total - ta
+        else:
+            ta = min(1, total); tb = total - ta
+        assert ta >= 0 and tb >= 0 and ta + tb == total
+        assign(a, ta); assign(b, tb)
+
+    assign(0, prob[0])
+    ids = np.array(sorted(stat), dtype=np.int32)
+    return ids, np.array([stat[i] for i in ids], dtype=np.int32)
+
+
 def read_weights(path, dtype, n=131857):
     b = open(path, "rb").read()
     i = b.find(struct.pack(">i", n))
@@ -151,7 +190,13 @@ def read_dr_mapping(path):
 def main():
     tree = read_tree(os.path.join(REF, "data/jtm/example_tree.bin"))
     assert tree["max_level"] == 12 and len(tree["leaf_ids"]) == 3706
+    tree["stat_ids"], tree["stat_counts"] = derive_stat(tree)
     np.savez_compressed(os.path.join(OUT, "tdm_tree.npz"), **tree)
+    import hashlib
+    import json
+    raw = open(os.path.join(REF, "data/jtm/example_tree.bin"), "rb").read()
+    json.dump({"file": "data/jtm/example_tree.bin", "bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest()},
+              open(os.path.join(OUT, "tdm_tree_file.json"), "w"))
     w32 = read_weights(os.path.join(REF, "data/jtm/example_model.bin"), ">f4")
     assert abs(float(w32[-1]) - (-0.1667024)) < 1e-7
     np.save(os.path.join(OUT, "din_f32.npy"), w32.astype("<f4"))
@@ -160,6 +205,23 @@ def main():
     np.save(os.path.join(OUT, "din_f64.npy"), w64.astype("<f8"))
     m = np.loadtxt(os.path.join(REF, "data/otm/example_mapping.txt"), dtype=np.int64)
     np.save(os.path.join(OUT, "otm_mapping.npy"), m.astype(np.int32))
+    # data/example_data.csv (user,item,label,timestamp,genre; 100 000 MovieLens-1M interactions): rows in stable
+    # timestamp order (timestamps themselves dropped: only their order matters to TreeInit.getUserInteracted) and
+    # the distinct (item, category index) pairs in file order (TreeInit.initializeTree / readFile).
+    us, its, ts, cats, cd = [], [], [], [], {}
+    for line in open(os.path.join(REF, "data/example_data.csv")):
+        arr = line.strip().split(",")
+        if len(arr) != 5 or not arr[0].isdigit():
+            continue
+        us.append(int(arr[0])); its.append(int(arr[1])); ts.append(int(arr[3]))
+        cats.append(cd.setdefault(arr[4], len(cd)))
+    order = np.argsort(np.array(ts), kind="stable")
+    seen, ui, uc = set(), [], []
+    for it, c in zip(its, cats):
+        if it not in seen:
+            seen.add(it); ui.append(it); uc.append(c)
+    np.savez_compressed(os.path.join(OUT, "example_data.npz"), user=np.array(us, np.int16)[order],
+                        item=np.array(its, np.int16)[order], uniq_item=np.array(ui, np.int16), uniq_cat=np.array(uc, np.int8))
     dr = read_dr_mapping(os.path.join(REF, "data/dr/example_mapping.bin"))
     assert dr["paths"].shape == (3325, 2, 3) and dr["paths"].max() < 100
     np.savez_compressed(os.path.join(OUT, "dr_mapping.npz"), **dr)
