@@ -15,7 +15,7 @@ from .engine import Engine, _i32, _p
 
 class JTM:
     def __init__(self, engine: Engine, leaf_item_ids, leaf_codes, max_level, item_rows, gap=2, seq_len=10,
-                 hierarchical=False, min_level=0, use_mask=True):
+                 hierarchical=False, min_level=0, use_mask=True, dist=None):
         """item_rows: dict item id -> int array [n_rows * seq_len] (itemSequenceMap, TreeLearning.scala:34-46)."""
         self.engine = engine
         self.items = np.sort(_i32(leaf_item_ids))
@@ -23,6 +23,7 @@ class JTM:
         self.item_code = np.array([lut[int(i)] for i in self.items], np.int32)      # code in the CURRENT tree
         self.max_level, self.gap, self.L = int(max_level), int(gap), int(seq_len)
         self.hierarchical, self.min_level, self.use_mask = bool(hierarchical), int(min_level), bool(use_mask)
+        self.dist = dist              # torch.distributed: items sharded over ranks, weights all-gathered (sharding.py)
         off = np.zeros(self.items.size + 1, np.int64)
         rows = []
         for k, it in enumerate(self.items.tolist()):
@@ -33,16 +34,27 @@ class JTM:
         self.row_off = off
         self.row_ids = _i32(np.concatenate(rows)) if off[-1] > 0 else np.zeros(self.L, np.int32)
 
-    def child_weights(self, item_node, old_level, level):
-        n = self.items.size
+    def weights_range(self, item_node, old_level, level, lo, hi):
+        """TreeLearning.aggregateWeights for the items [lo, hi) of the ascending-id item list (their rows only)."""
         nchild = 1 << (level - old_level)
-        w = np.empty((n, nchild), np.float32)
         node = _i32(item_node)
-        self.engine._chk(N.lib().dm_jtm_child_weights(self.engine._h, _p(self.row_off, N.i64p), _p(self.row_ids, N.i32p),
-                                                      _p(node, N.i32p), n, self.L, old_level, level,
-                                                      int(self.hierarchical), self.min_level, int(self.use_mask),
-                                                      _p(w, N.f32p)))
-        return w
+        n = hi - lo
+        w = np.empty((max(n, 1), nchild), np.float32)
+        if n == 0:
+            return w[:0]
+        off = np.ascontiguousarray(self.row_off[lo:hi + 1] - self.row_off[lo])
+        r0, r1 = int(self.row_off[lo]), int(self.row_off[hi])
+        rows = np.ascontiguousarray(self.row_ids[r0 * self.L:max(r1, r0 + 1) * self.L])
+        sub = np.ascontiguousarray(node[lo:hi])
+        self.engine._chk(N.lib().dm_jtm_child_weights(self.engine._h, _p(off, N.i64p), _p(rows, N.i32p), _p(sub, N.i32p), n,
+                                                      self.L, old_level, level, int(self.hierarchical), self.min_level,
+                                                      int(self.use_mask), _p(w, N.f32p)))
+        return w[:n]
+
+    def child_weights(self, item_node, old_level, level):
+        """All items; with `dist` every rank scores its contiguous item range and the blocks are all-gathered."""
+        from .sharding import sharded_rows
+        return sharded_rows(lambda lo, hi: self.weights_range(item_node, old_level, level, lo, hi), self.items.size, self.dist)
 
     def rebalance(self, weights, old_node, node, old_level, level, max_assign):
         weights = np.ascontiguousarray(weights, np.float32)

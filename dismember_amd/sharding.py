@@ -55,3 +55,18 @@ def gather_results(local_ids, dist):
     objs = [None] * dist.get_world_size()
     dist.all_gather_object(objs, np.asarray(local_ids))
     return np.concatenate(objs, axis=0)
+
+
+def sharded_rows(compute, n_items, dist):
+    """Item-sharded evaluation of a per-item row function (JTM child weights): rank r computes
+    compute(lo, hi) -> [hi - lo, ...] for its contiguous item range and every rank receives the concatenation in item
+    order.  Each item's row is produced by exactly one rank with that rank's own sequential sums, so the result is
+    bit-identical to the single-rank run whatever the world size."""
+    if dist is None:
+        return np.asarray(compute(0, int(n_items)))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(n_items, rank, world)
+    mine = np.ascontiguousarray(compute(lo, hi))
+    objs = [None] * world
+    dist.all_gather_object(objs, mine)
+    return np.concatenate(objs, axis=0)

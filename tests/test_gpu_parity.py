@@ -346,6 +346,11 @@ def test_jtm_child_weights_and_assignment(engine_fixture, oracle, oracle_tree, o
     w_gpu = jtm.child_weights(item_node, old_level, level)
     w_ref = oracle.jtm_child_weights(oracle_tree, oracle_din32, jtm.items, jtm.row_off, jtm.row_ids, item_node, 10,
                                      old_level, level, hierarchical=hierarchical, min_level=4)
+    # item shards (multi-GPU path: rank r scores items [lo, hi) only) reproduce the full matrix bit for bit
+    n = jtm.items.size
+    cuts = [0, n // 3, n // 3 + 1, n]
+    parts = [jtm.weights_range(item_node, old_level, level, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=0), w_gpu)
     seen = np.diff(jtm.row_off) > 0
     assert (w_gpu[~seen] == -1e6).all() and (w_ref[~seen] == -1e6).all()
     nrows = np.diff(jtm.row_off)[seen][:, None]

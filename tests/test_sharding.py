@@ -110,3 +110,45 @@ def test_two_rank_gradient_exchange():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert all(n == 2 and dense_ok and table_ok for _, n, dense_ok, table_ok in out)
+
+
+# ---- item-sharded JTM child weights (2 gloo ranks; the per-item row function stands in for the GPU scorer) ----
+def _jtm_rows(lo, hi):
+    i = np.arange(lo, hi, dtype=np.float64)[:, None]
+    return (np.sin(i * 0.37 + np.arange(4)[None, :]) * 1000).astype(np.float32)
+
+
+def _jtm_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from dismember_amd import sharding
+    dist, r, w, _ = sharding.init_distributed("gloo")
+    calls = []
+
+    def compute(lo, hi):
+        calls.append((lo, hi))
+        return _jtm_rows(lo, hi)
+
+    full = sharding.sharded_rows(compute, 37, dist)
+    q.put((r, calls, bool(np.array_equal(full, _jtm_rows(0, 37)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_item_sharded_rows():
+    import torch.multiprocessing as mp
+    from dismember_amd import sharding
+    assert np.array_equal(sharding.sharded_rows(_jtm_rows, 5, None), _jtm_rows(0, 5))     # single rank: whole range
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_jtm_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert out[0][1] == [(0, 19)] and out[1][1] == [(19, 37)]        # each rank scored only its own items
+    assert out[0][2] and out[1][2]                                     # and both hold the bit-identical full matrix
