@@ -742,7 +742,8 @@ static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, con
                           const int64_t *d_coff, const int32_t *d_cids, int32_t *d_ids, float *d_scores, int32_t *d_counts,
                           int trace_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn) {
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "tdm beam search: tree, id maps and weights must be loaded first");
-  if (U <= 0 || L <= 0 || L > DM_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..16)");
+  if (U < 0 || L <= 0 || L > DM_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..16)");
+  if (U == 0) return DM_OK;          // an empty batch is not an error
   if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: tree codes exceed the embedding table (embeddingLookup would fail)");
   if (h->max_code >= h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: id map codes exceed the embedding table");
   int start, level;
@@ -800,6 +801,7 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
 static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, const dm_tdm_search_opts *opts,
                            const int64_t *coff, const int32_t *cids, int32_t *out_ids, float *out_scores,
                            int32_t *out_counts, int max_levels, int32_t *tc, float *ts, int32_t *tn) {
+  if (U == 0 && L > 0 && opts && opts->beam > 0 && opts->topk > 0) return DM_OK;          // an empty batch is not an error
   if (!seq || !opts || !out_ids || !out_scores || !out_counts || U <= 0 || L <= 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: bad arguments");
   if (opts->beam <= 0 || opts->topk <= 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: beam and topk must be positive");
   if ((coff == nullptr) != (cids == nullptr) && coff && coff[U] > 0) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search: consumed_off / consumed_ids must both be given");
@@ -874,6 +876,7 @@ static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L
                            int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels, int32_t *tc,
                            float *ts, int32_t *tn) {
   if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_otm_beam_search: weights not loaded");
+  if (U == 0 && L > 0 && L <= DM_MAXL && beam > 0) return DM_OK;          // an empty batch is not an error
   if (!seq_codes || !out_node_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
     return fail(h, DM_ERR_INVALID, "dm_otm_beam_search: bad arguments");
   if ((((int64_t)1) << (leaf_level + 1)) - 1 > h->num_index) return fail(h, DM_ERR_INDEX, "dm_otm_beam_search: leaf level exceeds the embedding table");
@@ -957,6 +960,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
                            int32_t *out_item_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_bruteforce_topk: tree, id maps and weights must be loaded first");
+  if (U == 0 && L > 0 && L <= DM_MAXL && topk > 0 && topk <= 256) return DM_OK;          // an empty batch is not an error
   if (!seq_item_ids || !out_item_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || topk <= 0 || topk > 256)
     return fail(h, DM_ERR_INVALID, "dm_tdm_bruteforce_topk: bad arguments (topk must be 1..256)");
   if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "dm_tdm_bruteforce_topk: tree codes exceed the embedding table");

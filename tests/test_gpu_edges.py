@@ -1,0 +1,149 @@
+"""Edge cases and full-size properties (GPU): empty batches, history lengths 1..16, extreme beams, and — at BASELINE.json's
+config-2 / config-5 sizes, where the CPU oracle cannot follow — properties that do not depend on the size."""
+import numpy as np
+import pytest
+
+from dismember_amd import synth
+from helpers import random_din_weights, random_histories, synthetic_tree
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _engine(t, w, E):
+    from dismember_amd import Engine
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"]))
+    eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(w, E, (1 << (int(t["max_level"]) + 1)) - 1)
+    return eng
+
+
+def test_empty_batches_are_not_errors():
+    rng = np.random.default_rng(0)
+    t = synthetic_tree(rng, 7, 100)
+    eng = _engine(t, random_din_weights(rng, 16, 255), 16)
+    e = np.zeros((0, 10), np.int32)
+    ids, sc, cnt = eng.tdm_beam_search(e, 8, 5)
+    assert ids.shape == (0, 5) and cnt.shape == (0,)
+    ids, sc, cnt = eng.tdm_bruteforce_topk(e, 5)
+    assert ids.shape[0] == 0
+    ids, sc, cnt = eng.otm_beam_search(e, 4, 7)
+    assert ids.shape[0] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("E,L", [(16, 1), (32, 3), (64, 12), (128, 13), (128, 16), (16, 16)])
+def test_history_lengths_1_to_16(oracle, E, L):
+    """L = 13..16 takes the 16-column key-fragment instantiation; positions >= L must not leak into the softmax."""
+    rng = np.random.default_rng(100 * E + L)
+    depth, n_items, beam = 9, 400, 24
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    odin = oracle.Din(w, E, L, NI)
+    eng = _engine(t, w, E)
+    seqs = random_histories(rng, t["leaf_ids"], 17, L, pad_prob=0.3)
+    seqs[0] = 0                                           # all padding
+    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, 20)
+    same = 0
+    for u in range(len(seqs)):
+        oi, osc = otree.recommend(odin, seqs[u], 20, beam)
+        if ids[u, :cnt[u]].tolist() == oi.tolist():
+            same += 1
+            assert (np.abs(sc[u, :cnt[u]] - osc) <= ATOL + RTOL * np.abs(osc)).all()
+    assert same >= len(seqs) - 1, same
+    with pytest.raises(Exception):
+        eng.tdm_beam_search(np.zeros((1, 17), np.int32), beam, 20)       # L > 16: DM_ERR_INVALID, not a wrong answer
+    eng.close()
+
+
+def test_extreme_beams(oracle):
+    rng = np.random.default_rng(5)
+    depth, n_items = 8, 150
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, 32, NI)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    odin = oracle.Din(w, 32, 10, NI)
+    eng = _engine(t, w, 32)
+    seqs = random_histories(rng, t["leaf_ids"], 6, 10)
+    for beam, topk in [(1, 1), (1, 50), (2, 3), (3, 400), (1000, 10)]:      # beam 1: greedy descent; beam >> tree; topk >> leaves
+        ids, sc, cnt = eng.tdm_beam_search(seqs, beam, topk)
+        for u in range(len(seqs)):
+            oi, osc = otree.recommend(odin, seqs[u], topk, beam)
+            assert cnt[u] == len(oi), (beam, topk, u)
+            assert (ids[u, cnt[u]:] == -1).all() or cnt[u] == topk
+            if ids[u, :cnt[u]].tolist() == oi.tolist():
+                assert (np.abs(sc[u, :cnt[u]] - osc) <= ATOL + RTOL * np.abs(osc)).all()
+    eng.close()
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 at full size (1M items, depth 20, E=128, beam 200): what must hold at any size."""
+    from dismember_amd import Engine
+    E, L, depth, items, beam, topk, U = 128, 10, 20, 1_000_000, 200, 200, 96
+    tree = synth.make_tree(items, depth, np.random.default_rng(synth.SEED))
+    eng = Engine(0)
+    eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth)
+    eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+    eng.load_weights_din_synthetic(E, (1 << (depth + 1)) - 1, synth.SEED, tree_depth=depth, rho=0.95)
+    seqs = synth.make_users(tree["leaf_ids"], U, L, np.random.default_rng(3))
+    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, topk)
+    ids2, sc2, cnt2 = eng.tdm_beam_search(seqs, beam, topk)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc, sc2) and np.array_equal(cnt, cnt2)      # deterministic
+    leaf_set = set(tree["leaf_ids"].tolist())
+    code_of = dict(zip(tree["leaf_ids"].tolist(), tree["leaf_codes"].tolist()))
+    for u in range(U):
+        r = ids[u, :cnt[u]]
+        assert cnt[u] == topk and len(set(r.tolist())) == topk and set(r.tolist()) <= leaf_set
+        assert (np.diff(sc[u]) <= 0).all()
+    # the beam kernel's scores are the general forward's scores of the same (leaf, history) rows
+    for u in (0, 17, 95):
+        codes = np.array([code_of[int(i)] for i in ids[u]], np.int32)
+        hist, _ = eng.id_to_code(seqs[u])
+        pad = np.flatnonzero(np.tile(hist < 0, topk)).astype(np.int32)
+        ref = eng.din_forward(codes, np.tile(hist, (topk, 1)), pad, L=L)
+        assert (np.abs(sc[u] - ref) <= ATOL + RTOL * np.abs(ref)).all()
+    # brute force bounds the beam: its k-th best score is >= the beam's k-th best, its best is >= the beam's best
+    bids, bsc, bcnt = eng.tdm_bruteforce_topk(seqs[:8], topk)
+    for u in range(8):
+        assert (bsc[u, :topk] + ATOL + RTOL * np.abs(bsc[u, :topk]) >= sc[u]).all()
+        hit = set(ids[u].tolist()) & set(bids[u].tolist())
+        # every common item carries the same score on both sides
+        lut = dict(zip(bids[u].tolist(), bsc[u].tolist()))
+        for i, s in zip(ids[u].tolist(), sc[u].tolist()):
+            if i in hit:
+                assert abs(s - lut[i]) <= ATOL + RTOL * abs(lut[i])
+    # a wider beam never loses the narrower beam's best item
+    ids3, sc3, _ = eng.tdm_beam_search(seqs[:16], 2 * beam, topk)
+    assert (sc3[:, 0] + ATOL + RTOL * np.abs(sc3[:, 0]) >= sc[:16, 0]).all()
+    eng.close()
+
+
+def test_full_size_properties_config5():
+    """BASELINE config 5 at full size (Deep-Retrieval D=3, K=1000, beam 50, E=128, 10M items, f32)."""
+    from dismember_amd import Engine
+    E, L, K, D, items, beam, U = 128, 10, 1000, 3, 10_000_000, 50, 256
+    eng = Engine(0)
+    eng.dr_load_model_synthetic(E, L, K, D, items, synth.SEED, scale=0.05, rerank=False)
+    rng = np.random.default_rng(9)
+    seqs = rng.integers(0, items, size=(U, L)).astype(np.int32)
+    seqs[rng.random((U, L)) < 0.2] = -1
+    seqs[0] = -1
+    p, pr, cnt = eng.dr_beam_search(seqs, beam)
+    p2, pr2, _ = eng.dr_beam_search(seqs, beam)
+    assert np.array_equal(p, p2) and np.array_equal(pr, pr2)
+    assert (cnt == beam).all() and ((p >= 0) & (p < K)).all()
+    assert (np.diff(pr, axis=1) <= 0).all() and (pr > 0).all() and (pr.sum(axis=1) <= 1 + 1e-5).all()
+    codes = (p[..., 0].astype(np.int64) * K + p[..., 1]) * K + p[..., 2]
+    assert all(len(set(row.tolist())) == beam for row in codes)
+    # prefix property: the top path of a wider beam is at least as probable; a beam of 1 is the greedy path
+    g, gp, _ = eng.dr_beam_search(seqs[:32], 1)
+    w, wp, _ = eng.dr_beam_search(seqs[:32], 4 * beam)
+    assert (wp[:, 0] >= pr[:32, 0] * (1 - 1e-5)).all() and (pr[:32, 0] >= gp[:, 0] * (1 - 1e-5)).all()
+    # the beam's own best path contains the greedy first node whenever the greedy path is the best path
+    same = (g[:, 0, :] == p[:32, 0, :]).all(axis=1)
+    assert np.allclose(gp[same, 0], pr[:32][same, 0], rtol=1e-5)
+    eng.close()
