@@ -153,7 +153,7 @@ def main():
         kq = (L + 3) // 4
         flops_own = 2 * (E * E + 2 * L * E + E)                     # this formulation, per scored row
         flops_ref = 2 * (2 * L * E + 3 * E * E + E)                 # SURVEY.md §8d, reference formulation
-        mfma_issued = ((E // 16) * 4 + 4 * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0   # S^T + P x G (4 k-steps) + main chain
+        mfma_issued = ((E // 16) * 4 + kq * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0   # S^T + P x G (ceil(L/4) k-steps) + main chain
         ach = rows * flops_own / (avg_ms * 1e-3) / 1e12
         res = {
             "metric": "beam-search users/sec (TDM serve, 1M-item depth-20 tree, 128-d, beam 200)",
