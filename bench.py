@@ -181,11 +181,11 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01b_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01c_summary.json")))
             pw = prof["bench_line_under_profiler"]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01b_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                res["roofline"]["traffic_source"] = ("profiles/r01c_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                      "(separate passes), bytes per launch, FETCH x2 gfx950 correction")
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         except Exception:
