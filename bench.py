@@ -31,8 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--users", type=int, default=32768, help="users per step per GPU")
-    ap.add_argument("--items", type=int, default=1_000_000)
-    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--items", type=int, default=10_000_000)
+    ap.add_argument("--depth", type=int, default=24)
     ap.add_argument("--embed", type=int, default=128)
     ap.add_argument("--beam", type=int, default=200)
     ap.add_argument("--topk", type=int, default=200)
@@ -40,10 +40,14 @@ def parse():
     ap.add_argument("--cpu-users", type=int, default=-1, help="oracle sample size (-1 auto, 0 skip)")
     ap.add_argument("--rho", type=float, default=0.95, help="parent-child correlation of the synthetic node embeddings")
     ap.add_argument("--train", type=int, default=1, help="also time a training step (0 = skip)")
-    ap.add_argument("--big", type=int, default=1, help="also time the 10M-item depth-24 tree (BASELINE metric's catalogue size); 0 = skip")
+    ap.add_argument("--small", type=int, default=1, help="also time BASELINE configs[1] (1M-item depth-20 tree) and the training step on it; 0 = skip")
+    ap.add_argument("--big", type=int, default=None, help=argparse.SUPPRESS)   # old name of --small
     ap.add_argument("--dr", type=int, default=1, help="also time Deep-Retrieval serving (config 5: D=3, K=1000, beam=50, 10M items); 0 = skip")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.big is not None:
+        a.small = a.big
+    return a
 
 
 def effective_cores():
@@ -63,6 +67,26 @@ def effective_cores():
         except Exception:
             pass
     return n
+
+
+def host_mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+                break
+        else:
+            return 0
+        try:
+            lim = open("/sys/fs/cgroup/memory.max").read().strip()
+            cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            if lim != "max":
+                avail = min(avail, int(lim) - cur)
+        except Exception:
+            pass
+        return avail
+    except Exception:
+        return 0
 
 
 def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
@@ -156,7 +180,8 @@ def main():
         mfma_issued = ((E // 16) * 4 + kq * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0   # S^T + P x G (ceil(L/4) k-steps) + main chain
         ach = rows * flops_own / (avg_ms * 1e-3) / 1e12
         res = {
-            "metric": "beam-search users/sec (TDM serve, 1M-item depth-20 tree, 128-d, beam 200)",
+            "metric": "beam-search users/sec + recall@200 vs brute-force, 10M-item tree" if a.items == 10_000_000 else
+                      "beam-search users/sec (TDM serve, %d-item depth-%d tree, %d-d, beam %d)" % (a.items, depth, E, a.beam),
             "value": world * U * a.steps / dt,
             "unit": "users/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -164,7 +189,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
             "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
-                                   "beam=%d, topk=%d, L=%d, 1xMI355X per shard (BASELINE.json configs[1])"
+                                   "beam=%d, topk=%d, L=%d, 1xMI355X per shard (the catalogue BASELINE.json's metric names; 17.2 GB table)"
                                    % (a.items, depth, E, a.beam, a.topk, L),
                        "users_per_step_per_gpu": U, "parallelism": "user-sharded x%d, replicated table" % world,
                        "scored_rows_per_user": rows / U},
@@ -181,11 +206,11 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01c_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01d_summary.json")))
             pw = prof["bench_line_under_profiler"]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01c_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                res["roofline"]["traffic_source"] = ("profiles/r01d_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                      "(separate passes), bytes per launch, FETCH x2 gfx950 correction")
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         except Exception:
@@ -196,7 +221,12 @@ def main():
             rec = [len(set(ids[u, :cnt[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]
             res["recall_at_%d_vs_bruteforce" % a.topk] = {"value": float(np.mean(rec)), "users": nr,
                                                         "definition": "|beam top-k  ∩  brute-force top-k| / k, same scorer weights"}
-        if world == 1 and a.cpu_users != 0:
+        table_bytes = (num_index * E + 3 * E * E + 2 * E + 1) * 4
+        if world == 1 and a.cpu_users != 0 and host_mem_available() < 2 * table_bytes + (8 << 30):
+            res["cpu_baseline_note"] = ("skipped on this catalogue: the oracle needs a %.1f GB host copy of the table and the host "
+                                        "reports %.1f GB available; see extra_1m_item_tree.cpu_baseline" %
+                                        (table_bytes / 1e9, host_mem_available() / 1e9))
+        elif world == 1 and a.cpu_users != 0:
             n_cpu = a.cpu_users
             w = eng.download_weights()
             base, outs = cpu_baseline(tree, w, E, L, num_index, seqs, a.beam, a.topk, n_cpu)
@@ -206,36 +236,13 @@ def main():
                        for u in range(len(ocnt)))
             res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
         res_main = res
-    # ---- extra: one data-parallel training step on the same catalogue (rows A10 + A12; every rank = one worker) ----
-    train = None
-    if a.train and (a.items, a.depth) == (1_000_000, 20):
-        from dismember_amd.trainer import TDMTrainer
-        neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 19, 22, 25, 30], np.int32)   # configs/tdm.conf
-        per = int(sum(1 + neg[l] for l in range(1, depth + 1)))
-        Tt = max(1, 8192 // per)                        # total_batch_size 8192 expanded rows per worker
-        tr = TDMTrainer(eng, neg, lr=1e-4, dist=dist, torch=torch, seed=synth.SEED)
-        trng = np.random.default_rng(synth.SEED + 7 + rank)
-        tseq = synth.make_users(tree["leaf_ids"], Tt, L, trng)
-        ttgt = trng.choice(tree["leaf_ids"], Tt).astype(np.int32)
-        tr.step(tseq, ttgt)
-        sync(); barrier()
-        t0 = time.perf_counter()
-        nts = 5
-        for _ in range(nts):
-            tloss = tr.step(tseq, ttgt)
-        sync(); barrier()
-        dtt = sharding.max_over_ranks(time.perf_counter() - t0, dist)
-        nparam = num_index * E + 3 * E * E + 2 * E + 1
-        train = {"workload": "TDM train step: %d targets -> %d expanded rows per worker (level-wise negatives), DIN fwd+bwd, "
-                             "gradient exchange, dense Adam over %d parameters" % (Tt, Tt * per, nparam),
-                 "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
-                 "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world}
-    # ---- extra: the 10M-item depth-24 catalogue the metric names (17.2 GB table, replicated per GPU) ----
-    big = None
-    if a.big and (a.items, a.depth) == (1_000_000, 20):
+    default_cfg = (a.items, a.depth) == (10_000_000, 24)
+    # ---- extra: BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel training step on it ----
+    small = train = None
+    if a.small and default_cfg:
         eng.dev_free(d_seq); eng.dev_free(d_ids); eng.dev_free(d_sc); eng.dev_free(d_cnt)
         eng.close()
-        depth2, items2 = 24, 10_000_000
+        depth2, items2 = 20, 1_000_000
         ni2 = (1 << (depth2 + 1)) - 1
         tree2 = synth.make_tree(items2, depth2, np.random.default_rng(synth.SEED))
         seqs2 = synth.make_users(tree2["leaf_ids"], U, L, np.random.default_rng(synth.SEED + 101 + rank))
@@ -256,22 +263,51 @@ def main():
         dt2 = sharding.max_over_ranks(time.perf_counter() - t0, dist)
         nl2, kms2 = eng.timing_get()
         rows2 = eng.last_scored_rows()
-        big = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (17.2 GB table)"
-                           % (items2, depth2, E, a.beam, a.topk),
-               "users_per_s": world * U * nst / dt2, "steps": nst, "ms_per_step": dt2 / nst * 1e3,
-               "scored_rows_per_user": rows2 / U,
-               "roofline_frac": rows2 * 2 * (E * E + 2 * L * E + E) / (kms2 / max(nl2, 1) * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS}
-        if a.recall_users > 0 and rank == 0:
-            nr = min(a.recall_users, 16)
+        small = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (BASELINE.json configs[1])"
+                             % (items2, depth2, E, a.beam, a.topk),
+                 "users_per_s": world * U * nst / dt2, "steps": nst, "ms_per_step": dt2 / nst * 1e3,
+                 "scored_rows_per_user": rows2 / U,
+                 "roofline_frac": rows2 * 2 * (E * E + 2 * L * E + E) / (kms2 / max(nl2, 1) * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS}
+        if rank == 0:
             ids2 = np.empty((U, a.topk), np.int32); cnt2 = np.empty(U, np.int32)
             eng.d2h(ids2, d_ids); eng.d2h(cnt2, d_cnt)
-            bids, _, bcnt = eng.tdm_bruteforce_topk(seqs2[:nr], a.topk)
-            big["recall_at_%d_vs_bruteforce" % a.topk] = float(np.mean(
-                [len(set(ids2[u, :cnt2[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]))
-            big["recall_users"] = nr
+            if a.recall_users > 0:
+                nr = min(a.recall_users, U)
+                bids, _, bcnt = eng.tdm_bruteforce_topk(seqs2[:nr], a.topk)
+                small["recall_at_%d_vs_bruteforce" % a.topk] = float(np.mean(
+                    [len(set(ids2[u, :cnt2[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]))
+                small["recall_users"] = nr
+            if world == 1 and a.cpu_users != 0 and "cpu_baseline" not in res_main:
+                base, outs = cpu_baseline(tree2, eng.download_weights(), E, L, ni2, seqs2, a.beam, a.topk, a.cpu_users)
+                oids, ocnt = outs
+                same = sum(int(cnt2[u] == ocnt[u] and np.array_equal(ids2[u, :cnt2[u]], oids[u, :ocnt[u]])) for u in range(len(ocnt)))
+                base["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
+                small["cpu_baseline"] = base
+        if a.train:
+            from dismember_amd.trainer import TDMTrainer
+            neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 19, 22, 25, 30], np.int32)   # configs/tdm.conf
+            per = int(sum(1 + neg[l] for l in range(1, depth2 + 1)))
+            Tt = max(1, 8192 // per)                        # total_batch_size 8192 expanded rows per worker
+            tr = TDMTrainer(eng, neg, lr=1e-4, dist=dist, torch=torch, seed=synth.SEED)
+            trng = np.random.default_rng(synth.SEED + 7 + rank)
+            tseq = synth.make_users(tree2["leaf_ids"], Tt, L, trng)
+            ttgt = trng.choice(tree2["leaf_ids"], Tt).astype(np.int32)
+            tr.step(tseq, ttgt)
+            sync(); barrier()
+            t0 = time.perf_counter()
+            nts = 5
+            for _ in range(nts):
+                tloss = tr.step(tseq, ttgt)
+            sync(); barrier()
+            dtt = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+            nparam = ni2 * E + 3 * E * E + 2 * E + 1
+            train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives), "
+                                 "DIN fwd+bwd, gradient exchange, dense Adam over %d parameters" % (Tt, Tt * per, nparam),
+                     "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
+                     "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world}
     # ---- extra: Deep-Retrieval serving, BASELINE config 5 (row A13): D=3, K=1000, beam=50, 10M items ----
     dr = None
-    if a.dr and (a.items, a.depth) == (1_000_000, 20):
+    if a.dr and default_cfg:
         eng.close()
         eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
         Kd, Dd, beam_d, topk_d, items_d, Ud = 1000, 3, 50, 10, 10_000_000, 16384
@@ -325,8 +361,8 @@ def main():
     if rank == 0:
         if dr is not None:
             res_main["extra_deep_retrieval"] = dr
-        if big is not None:
-            res_main["extra_10m_item_tree"] = big
+        if small is not None:
+            res_main["extra_1m_item_tree"] = small
         if train is not None:
             res_main["extra_train_step"] = train
         print(json.dumps(res_main))
