@@ -1,0 +1,98 @@
+// Exercises the C++ host facade (include/dismember.hpp) on the GPU; driven by tests/test_gpu_cpp_facade.py, which
+// writes the inputs as raw arrays into a directory and compares this program's JSON output with the Python facade /
+// the CPU oracle.  usage: facade_test <dir>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "dismember.hpp"
+
+template <typename T>
+static std::vector<T> rd(const std::string &dir, const std::string &name) {
+  std::ifstream f(dir + "/" + name, std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("missing " + name);
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  std::vector<T> v((size_t)n / sizeof(T));
+  f.read((char *)v.data(), n);
+  return v;
+}
+
+static void printRecs(const char *key, const dm::Recs &r, bool last = false) {
+  std::printf("\"%s\": [", key);
+  for (size_t i = 0; i < r.size(); i++) std::printf("%s[%d, %.17g]", i ? ", " : "", r[i].first, r[i].second);
+  std::printf("]%s\n", last ? "" : ",");
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  const std::string d = argv[1];
+  try {
+    const auto meta = rd<int32_t>(d, "meta.i32");       // max_level, E, topk, beam, L
+    const int maxLevel = meta[0], E = meta[1], topk = meta[2], beam = meta[3], L = meta[4];
+    dm::Engine eng(0);
+    eng.loadTree(rd<int32_t>(d, "codes.i32"), rd<int32_t>(d, "ids.i32"), rd<uint8_t>(d, "is_leaf.u8"), maxLevel,
+                 rd<int32_t>(d, "leaf_ids.i32"), rd<int32_t>(d, "leaf_codes.i32"));
+    eng.loadWeightsDin(rd<float>(d, "w32.f32"), E, ((int64_t)1 << (maxLevel + 1)) - 1);
+    const auto query = rd<int32_t>(d, "query.i32");
+    const auto consumed = rd<int32_t>(d, "consumed.i32");
+    dm::TDM tdm(eng, "DIN");
+    std::printf("{\n");
+    printRecs("tdm_recommend", tdm.recommend(query, topk, beam));
+    {
+      const auto a = tdm.recommendItems(query, topk, beam);
+      const auto b = tdm.recommendItems(query, topk, beam, &consumed);
+      std::printf("\"items_plain\": [");
+      for (size_t i = 0; i < a.size(); i++) std::printf("%s%d", i ? ", " : "", a[i]);
+      std::printf("],\n\"items_consumed\": [");
+      for (size_t i = 0; i < b.size(); i++) std::printf("%s%d", i ? ", " : "", b[i]);
+      std::printf("],\n");
+    }
+    {
+      const auto seqs = rd<int32_t>(d, "batch.i32");
+      const auto r = tdm.recommendBatch(seqs, (int64_t)seqs.size() / L, L, topk, beam);
+      std::printf("\"batch_first_ids\": [");
+      for (size_t u = 0; u < r.size(); u++) std::printf("%s%d", u ? ", " : "", r[u].empty() ? -1 : r[u][0].first);
+      std::printf("],\n");
+    }
+    {   // metrics
+      double p, r, n;
+      dm::Metrics::computeMetrics({7, 1, 9, 4}, {9, 7, 100}, p, r, n);
+      std::printf("\"metrics\": [%.17g, %.17g, %.17g],\n", p, r, n);
+    }
+    {   // JTM on the same tree: rows per item
+      const auto rowItems = rd<int32_t>(d, "jtm_row_items.i32");     // item id per row
+      const auto rows = rd<int32_t>(d, "jtm_rows.i32");              // [n_rows x L]
+      std::map<int32_t, std::vector<int32_t>> itemRows;
+      for (size_t k = 0; k < rowItems.size(); k++)
+        itemRows[rowItems[k]].insert(itemRows[rowItems[k]].end(), rows.begin() + (ptrdiff_t)(k * (size_t)L), rows.begin() + (ptrdiff_t)((k + 1) * (size_t)L));
+      dm::JTM jtm(eng, rd<int32_t>(d, "leaf_ids.i32"), rd<int32_t>(d, "leaf_codes.i32"), maxLevel, itemRows, 2, L);
+      const auto proj = jtm.optimize();
+      std::printf("\"jtm_projection\": [");
+      bool first = true;
+      for (auto &kv : proj) { std::printf("%s[%d, %d]", first ? "" : ", ", kv.first, kv.second); first = false; }
+      std::printf("],\n");
+    }
+    {   // OTM: f64 weights, item -> node mapping
+      dm::Engine e2(0);
+      const auto w64 = rd<double>(d, "w64.f64");
+      e2.loadWeightsDin(w64, E, ((int64_t)1 << (maxLevel + 1)) - 1);
+      const auto m = rd<int32_t>(d, "otm_mapping.i32");              // pairs (item, node)
+      std::map<int32_t, int32_t> mp;
+      for (size_t i = 0; i + 1 < m.size(); i += 2) mp[m[i]] = m[i + 1];
+      dm::OTM otm(e2, mp);
+      printRecs("otm_recommend", otm.recommend(rd<int32_t>(d, "otm_query.i32"), topk, beam));
+    }
+    {   // error mapping
+      int code = 0;
+      try { tdm.recommend(std::vector<int32_t>(40, 1), topk, beam); } catch (const dm::Error &e) { code = e.code; }
+      std::printf("\"error_code_L40\": %d\n", code);
+    }
+    std::printf("}\n");
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "facade_test: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

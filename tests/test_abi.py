@@ -62,3 +62,15 @@ def test_level_start_integer(native):
         assert lib.dm_level_start(n, C.byref(s), C.byref(l)) == 0
         assert (s.value, l.value) == exp
     assert lib.dm_level_start(0, C.byref(s), C.byref(l)) != 0
+
+
+def test_cpp_host_facade_compiles_and_links(tmp_path):
+    """include/dismember.hpp (the C++ mirror of the Scala facades) builds against the C ABI with a plain host compiler:
+    no HIP headers, no torch (linking only; nothing runs without a GPU)."""
+    import subprocess
+    exe = str(tmp_path / "facade_test")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "dismember_amd"), "-ldismember_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dismember_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
