@@ -84,6 +84,34 @@ int main(int argc, char **argv) {
       dm::OTM otm(e2, mp);
       printRecs("otm_recommend", otm.recommend(rd<int32_t>(d, "otm_query.i32"), topk, beam));
     }
+    {   // Deep-Retrieval: model + path table through the C ABI, recommend through the facade
+      const auto dm_ = rd<int32_t>(d, "dr_meta.i32");                // E, L, K, D, num_item, beam, topk
+      const int dE = dm_[0], dL = dm_[1], dK = dm_[2], dD = dm_[3], dn = dm_[4];
+      dm::Engine e3(0);
+      const auto emb = rd<double>(d, "dr_layer_emb.f64");
+      std::vector<std::vector<double>> W, B;
+      std::vector<const void *> wp, bp;
+      for (int i = 0; i < dD; i++) {
+        W.push_back(rd<double>(d, "dr_w" + std::to_string(i) + ".f64"));
+        B.push_back(rd<double>(d, "dr_b" + std::to_string(i) + ".f64"));
+      }
+      for (int i = 0; i < dD; i++) { wp.push_back(W[(size_t)i].data()); bp.push_back(B[(size_t)i].data()); }
+      const auto remb = rd<double>(d, "dr_rerank_emb.f64"), rw = rd<double>(d, "dr_rerank_w.f64"), rb = rd<double>(d, "dr_rerank_b.f64");
+      const auto sw = rd<double>(d, "dr_softmax_w.f64"), sb = rd<double>(d, "dr_softmax_b.f64");
+      dm_dr_model m{};
+      m.dtype = DM_F64; m.on_device = 0; m.embed = dE; m.seq_len = dL; m.num_node = dK; m.num_layer = dD; m.num_item = dn;
+      m.layer_emb = emb.data(); m.layer_w = wp.data(); m.layer_b = bp.data();
+      m.rerank_emb = remb.data(); m.rerank_w = rw.data(); m.rerank_b = rb.data(); m.softmax_w = sw.data(); m.softmax_b = sb.data();
+      e3.check(dm_dr_load_model(e3.handle(), &m));
+      const auto pn = rd<int32_t>(d, "dr_path_nodes.i32");
+      const auto po = rd<int64_t>(d, "dr_item_off.i64");
+      const auto pi = rd<int32_t>(d, "dr_items.i32");
+      e3.check(dm_dr_load_path_items(e3.handle(), pn.data(), (int64_t)po.size() - 1, po.data(), pi.data()));
+      std::map<int32_t, int32_t> idmap;
+      for (int i = 0; i < dn; i++) idmap[1000 + 3 * i] = i;          // item = 1000 + 3 * id
+      dm::DeepRetrieval dr(e3, idmap);
+      printRecs("dr_recommend", dr.recommend(rd<int32_t>(d, "dr_query.i32"), dm_[6], dm_[5]));
+    }
     {   // error mapping
       int code = 0;
       try { tdm.recommend(std::vector<int32_t>(40, 1), topk, beam); } catch (const dm::Error &e) { code = e.code; }

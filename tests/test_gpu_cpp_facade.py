@@ -41,6 +41,22 @@ def test_cpp_facade_matches_python_mirror_and_oracle(tmp_path, fixture_tree, fix
                           ("consumed.i32", consumed, np.int32), ("batch.i32", batch, np.int32), ("jtm_row_items.i32", row_items, np.int32),
                           ("jtm_rows.i32", rows, np.int32), ("otm_mapping.i32", omap, np.int32), ("otm_query.i32", otm_query, np.int32)]:
         np.ascontiguousarray(arr, dtype=dt).tofile(d / name)
+    # Deep-Retrieval inputs (fp64 model, like the reference)
+    from dismember_amd import synth
+    dE, dL, dK, dD, dn, dbeam, dtopk = 16, 6, 10, 3, 300, 30, 8
+    drng = np.random.default_rng(12)
+    dw = synth.make_dr_model(dn, dK, dD, dL, dE, drng)
+    dpi = synth.dr_path_items(synth.make_dr_paths(dn, dK, dD, 2, drng))
+    np.array([dE, dL, dK, dD, dn, dbeam, dtopk], np.int32).tofile(d / "dr_meta.i32")
+    dw["layer_emb"].tofile(d / "dr_layer_emb.f64")
+    for i in range(dD):
+        dw["layer_w"][i].tofile(d / ("dr_w%d.f64" % i)); dw["layer_b"][i].tofile(d / ("dr_b%d.f64" % i))
+    for k in ("rerank_emb", "rerank_w", "rerank_b", "softmax_w", "softmax_b"):
+        dw[k].tofile(d / ("dr_%s.f64" % k))
+    dpi[0].astype(np.int32).tofile(d / "dr_path_nodes.i32"); dpi[1].astype(np.int64).tofile(d / "dr_item_off.i64")
+    dpi[2].astype(np.int32).tofile(d / "dr_items.i32")
+    dr_query_ids = drng.integers(0, dn, dL)
+    (1000 + 3 * dr_query_ids).astype(np.int32).tofile(d / "dr_query.i32")
     out = json.loads(subprocess.check_output([exe, str(d)], env=dict(os.environ), timeout=300))
 
     # ---- the Python mirror over the same library
@@ -77,4 +93,10 @@ def test_cpp_facade_matches_python_mirror_and_oracle(tmp_path, fixture_tree, fix
     pyo = otm.recommend(otm_query, topk, beam)
     assert [r[0] for r in out["otm_recommend"]] == [r[0] for r in pyo]
     assert np.allclose([r[1] for r in out["otm_recommend"]], [r[1] for r in pyo], rtol=0, atol=1e-15)
+    # ---- Deep-Retrieval: the fp64 oracle's recommendation, mapped through the same item <-> id maps
+    from oracle import pyoracle as po
+    orc = po.DeepRetrieval(dw, dE, dL, dK, dD, dn, path_items=dpi)
+    oi, osc = orc.recommend(dr_query_ids.astype(np.int32), dtopk, dbeam)
+    assert [r[0] for r in out["dr_recommend"]] == (1000 + 3 * oi).tolist() and len(oi) > 0
+    assert np.allclose([r[1] for r in out["dr_recommend"]], 1.0 / (1.0 + np.exp(-osc)), rtol=1e-9)
     assert out["error_code_L40"] == -1                       # DM_ERR_INVALID surfaces as dm::Error
