@@ -149,6 +149,15 @@ int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *r
 int dm_jtm_rebalance(dm_handle_t h, const float *weights, const int32_t *old_node, int64_t n, int32_t node, int old_level,
                      int level, int max_assign, int32_t *out_node);
 
+/* OTM twin (otm/src/main/scala/com/mass/otm/tree/TreeConstruction.scala): the item sequences hold NODE ids (-1 =
+ * paddingIdx, :218-232), the scorer runs in the loaded dtype (fp64 in the reference) and sums are double:
+ * dm_otm_child_weights = aggregateWeights (:194-212) per child of getChildrenAtLevel (:281-285);
+ * dm_otm_rebalance     = sortNodeWeights (:180-192) + first choice + reBalance (:304-352), same logic as the JTM one. */
+int dm_otm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *row_codes, const int32_t *item_node,
+                         int64_t n_items, int L, int old_level, int level, int use_mask, double *weights);
+int dm_otm_rebalance(dm_handle_t h, const double *weights, const int32_t *old_node, int64_t n, int32_t node, int old_level,
+                     int level, int max_assign, int32_t *out_node);
+
 /* ---- training step (tdm/src/main/scala/com/mass/tdm/optim/LocalOptimizer.scala:58-187) ------------------
  * One handle == one worker (the reference's per-thread model clone).  A step is
  *   dm_train_forward_backward  == trainBatch (:139-162): zero-initialised gradients accumulate the mean-BCE
