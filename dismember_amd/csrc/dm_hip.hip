@@ -683,6 +683,7 @@ static int ensure_ws(dm_ctx *h, size_t bytes) {
 }
 
 static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
+  if (h->ev_used >= 4096) h->ev_used = 0;      // a service that never reads the timings keeps a bounded pool (oldest pairs are reused)
   if (h->ev_used == h->ev_pool.size()) {
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));

@@ -269,6 +269,7 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
 /* ---- measurement ----------------------------------------------------------- */
 /* HIP events on the handle's stream around every beam-search kernel launched since the last
  * reset: number of launches and their summed duration. */
+/* HIP-event pairs around the kernels launched since the last reset (at most the 4096 most recent launches) */
 int dm_kernel_timing_reset(dm_handle_t h);
 int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms);
 /* scored rows (node, user) pairs of the last beam-search call, for roofline accounting */
