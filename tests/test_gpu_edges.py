@@ -147,3 +147,34 @@ def test_full_size_properties_config5():
     same = (g[:, 0, :] == p[:32, 0, :]).all(axis=1)
     assert np.allclose(gp[same, 0], pr[:32][same, 0], rtol=1e-5)
     eng.close()
+
+
+def test_search_without_mask(oracle):
+    """useMask = false (TDM.apply for non-DIN model names, TDM.scala:26-29): padded history positions are zero rows that
+    DO take part in the softmax (score 0), in the beam kernel, the brute-force mode and the general forward alike."""
+    rng = np.random.default_rng(21)
+    depth, n_items, beam, E, L = 9, 400, 24, 64, 10
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    odin = oracle.Din(w, E, L, NI)
+    eng = _engine(t, w, E)
+    seqs = random_histories(rng, t["leaf_ids"], 12, L, pad_prob=0.4)
+    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, 20, use_mask=False)
+    idm, scm, _ = eng.tdm_beam_search(seqs, beam, 20, use_mask=True)
+    assert not np.array_equal(sc, scm)                       # the flag matters on padded histories
+    same = 0
+    for u in range(len(seqs)):
+        oi, osc = otree.recommend(odin, seqs[u], 20, beam, use_mask=False)
+        if ids[u, :cnt[u]].tolist() == oi.tolist():
+            same += 1
+            assert (np.abs(sc[u, :cnt[u]] - osc) <= ATOL + RTOL * np.abs(osc)).all()
+    assert same >= len(seqs) - 1
+    bids, bsc, bcnt = eng.tdm_bruteforce_topk(seqs[:3], 10, use_mask=False)
+    for u in range(3):
+        hist, _ = eng.id_to_code(seqs[u])
+        ref = eng.din_forward(t["leaf_codes"], np.tile(hist, (n_items, 1)), None, L=L)      # no mask indices: no masking
+        order = np.argsort(-ref, kind="stable")[:10]
+        assert (np.abs(bsc[u, :10] - ref[order]) <= ATOL + RTOL * np.abs(ref[order])).all()
+    eng.close()
