@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--users", type=int, default=32768, help="users per step per GPU")
+    ap.add_argument("--users", type=int, default=131072, help="users per step per GPU (x 8-10 steps = the 1M-user population of the target)")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--depth", type=int, default=24)
     ap.add_argument("--embed", type=int, default=128)
@@ -206,11 +206,11 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01d_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01e_summary.json")))
             pw = prof["bench_line_under_profiler"]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01d_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                res["roofline"]["traffic_source"] = ("profiles/r01e_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                      "(separate passes), bytes per launch, FETCH x2 gfx950 correction")
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         except Exception:
