@@ -74,3 +74,26 @@ def test_cpp_host_facade_compiles_and_links(tmp_path):
                            "-L" + os.path.join(ROOT, "dismember_amd"), "-ldismember_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "dismember_amd"), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+def test_null_handle_is_an_error_not_a_crash():
+    """Every entry point that takes a handle rejects NULL with DM_ERR_INVALID (no device needed)."""
+    import ctypes as C
+    from dismember_amd import _native as N
+    lib = N.lib()
+    skip = {"dm_version", "dm_device_count", "dm_create", "dm_last_error", "dm_level_start"}
+    checked = 0
+    for name, (restype, argtypes) in N.SIGNATURES.items():
+        if name in skip or not argtypes or argtypes[0] is not C.c_void_p:
+            continue
+        args = [None]
+        for t in argtypes[1:]:
+            if t in (C.c_int, C.c_int32, C.c_int64, C.c_size_t, C.c_uint64):
+                args.append(0)
+            elif t in (C.c_float, C.c_double):
+                args.append(0.0)
+            else:
+                args.append(None)
+        assert getattr(lib, name)(*args) == -1, name
+        checked += 1
+    assert checked >= 40
