@@ -1,0 +1,40 @@
+"""Randomised parity sweep (GPU): many small random configurations of the TDM search against the CPU oracle, through the
+trace replay contract (ids bit-exact on the GPU's scores, scores within tolerance).  Not part of the test suite; run
+by hand: python tools/fuzz_parity.py [n_configs] [seed]."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import random_din_weights, random_histories, synthetic_tree    # noqa: E402
+from test_gpu_parity import make_engine, replay_and_check                    # noqa: E402
+from oracle import pyoracle as po                                            # noqa: E402
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for c in range(n_cfg):
+    E = int(rng.choice([16, 32, 64, 128]))
+    depth = int(rng.integers(4, 12))
+    n_items = int(rng.integers(max(2, (1 << depth) // 3), (1 << depth) + 1))
+    beam = int(rng.integers(1, 300))
+    topk = int(rng.integers(1, 2 * beam + 2))
+    U = int(rng.integers(1, 20))
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    otree = po.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    odin = po.Din(w, E, 10, NI)
+    eng = make_engine(t, w, E)
+    seqs = random_histories(rng, t["leaf_ids"], U, 10, pad_prob=float(rng.random()) * 0.6, unknown_prob=0.05)
+    try:
+        replay_and_check(otree, odin, eng, seqs, beam, topk, use_mask=bool(rng.integers(0, 2)))
+    except AssertionError as e:
+        bad += 1
+        print("MISMATCH cfg", c, dict(E=E, depth=depth, n_items=n_items, beam=beam, topk=topk, U=U), str(e)[:300])
+    eng.close()
+print("configs", n_cfg, "mismatches", bad)
+sys.exit(1 if bad else 0)
