@@ -7,8 +7,9 @@ then ONE Adam step updates the shared weights.  Here a worker is a process with 
 weights); `exchange_gradients` makes every replica hold the same summed gradient, and every replica applies
 the same Adam step, so replicas stay bit-identical without a parameter broadcast:
   * dense block (att.W, l1.W, l1.b, l2.W, l2.b; 198 KB at E=128): all-reduce(sum)
-  * embedding gradients: row-sparse -> all-gather of (row index, gradient row) lists, then each rank adds the
-    other ranks' rows in rank order (never a ring over the 17 GB table).
+  * embedding gradients: row-sparse -> all-gather of (row index, gradient row) lists; every rank then rebuilds each touched
+    row as 0 + g_0 + g_1 + ... in rank order (its own contribution is subtracted first), so the sums are bit-identical on
+    all replicas for any number of workers (never a ring over the 17 GB table).
 """
 import ctypes as C
 
@@ -72,9 +73,14 @@ def exchange_gradients(port, dist, torch):
         all_grads = [torch.empty_like(pgrad) for _ in range(world)]
         dist.all_gather(all_rows, prow)
         dist.all_gather(all_grads, pgrad)
-        for r in range(world):                    # same order on every rank -> bit-identical replicas
-            if r != rank and int(sizes[r].item()) > 0:
-                k = int(sizes[r].item())
+        # Every replica must form each row's sum in the SAME order, or rows touched by three or more workers differ in
+        # the last bit between replicas ((g2 + g0) + g1 != (g0 + g1) + g2 in floating point).  So the rank's own
+        # contribution is taken out again (x + (-x) is exactly 0) and all contributions are added in rank order 0..W-1.
+        if rows.shape[0] > 0:
+            port.add_rows(rows, -grads)
+        for r in range(world):
+            k = int(sizes[r].item())
+            if k > 0:
                 port.add_rows(all_rows[r][:k], all_grads[r][:k])
     return world
 

@@ -53,7 +53,7 @@ def test_two_rank_gloo_sharding():
         assert slowest == 2.0 and shape == (101, 3) and ordered
 
 
-# ---- gradient exchange protocol of the data-parallel trainer (2 gloo ranks, numpy-backed fake engines) ----
+# ---- gradient exchange protocol of the data-parallel trainer (3 gloo ranks, torch-backed fake engines) ----
 class _FakePort:
     """Stands in for EngineGradPort: a dense block and a row-sparse embedding gradient held in torch CPU tensors."""
 
@@ -62,8 +62,8 @@ class _FakePort:
         self.torch = torch
         self.dense_block = torch.randn(37, generator=g)
         self.table = torch.zeros(n_rows, E)
-        idx = torch.randperm(n_rows, generator=g)[:12]
-        self.table[idx] = torch.randn(12, E, generator=g)
+        idx = torch.randperm(n_rows, generator=g)[:30]          # 30 of 50 rows: most rows are touched by several workers
+        self.table[idx] = torch.randn(30, E, generator=g) * (10.0 ** float(rank))     # magnitudes that make the order matter
         self.touched = idx.to(torch.int32)
 
     def dense(self):
@@ -91,12 +91,13 @@ def _exchange_worker(rank, world, port, q):
     n = exchange_gradients(mine, dist, torch)
     want_dense = sum(p.dense_block for p in [_FakePort(torch, k) for k in range(world)])
     want_table = sum(p.table for p in [_FakePort(torch, k) for k in range(world)])
-    q.put((r, n, bool(torch.allclose(mine.dense_block, want_dense)), bool(torch.allclose(mine.table, want_table))))
+    q.put((r, n, bool(torch.allclose(mine.dense_block, want_dense)), bool(torch.allclose(mine.table, want_table, rtol=1e-5, atol=1e-5)),
+           mine.table.numpy().tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_exchange():
+def test_three_rank_gradient_exchange_bit_identical_replicas():
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -104,12 +105,13 @@ def test_two_rank_gradient_exchange():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, q)) for r in range(3)]
     [p.start() for p in procs]
-    out = sorted(q.get(timeout=120) for _ in range(2))
+    out = sorted(q.get(timeout=120) for _ in range(3))
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert all(n == 2 and dense_ok and table_ok for _, n, dense_ok, table_ok in out)
+    assert all(n == 3 and dense_ok and table_ok for _, n, dense_ok, table_ok, _ in out)
+    assert out[0][4] == out[1][4] == out[2][4]          # every replica holds the same bits (rows summed in rank order)
 
 
 # ---- item-sharded JTM child weights (2 gloo ranks; the per-item row function stands in for the GPU scorer) ----
