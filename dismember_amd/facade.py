@@ -28,7 +28,8 @@ class TDM:
         seq = np.asarray(sequence, dtype=np.int32)
         single = seq.ndim == 1
         ids, sc, cnt = self.engine.tdm_beam_search(seq, candidate_num, topk, use_mask=self.use_mask)
-        out = [[(int(ids[u, i]), float(sigmoid(sc[u, i]))) for i in range(cnt[u])] for u in range(ids.shape[0])]
+        prob = sigmoid(sc)                                   # one vectorised pass, in double
+        out = [list(zip(ids[u, :cnt[u]].tolist(), prob[u, :cnt[u]].tolist())) for u in range(ids.shape[0])]
         return out[0] if single else out
 
     def recommend_items(self, sequence, topk, candidate_num, consumed_items=None):

@@ -1,0 +1,25 @@
+"""Single-request latency of the facade calls (the reference prints "Average recommend time": one user, topk 10, beam 20,
+10 warm-up + 100 timed calls — examples/.../tdm/package.scala:119-123)."""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dismember_amd import Engine, TDM
+g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+t = np.load(os.path.join(g, "tdm_tree.npz")); w = np.load(os.path.join(g, "din_f32.npy"))
+eng = Engine(0)
+eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+eng.load_weights_din(w, 16, 8191)
+tdm = TDM(eng, "din")
+q = np.array([0, 0, 2126, 204, 3257, 3439, 996, 1681, 3438, 1882], np.int32)
+for _ in range(10):
+    tdm.recommend(q, 10, 20)
+t0 = time.perf_counter()
+for _ in range(100):
+    tdm.recommend(q, 10, 20)
+print("TDM.recommend (1 user, topk 10, beam 20, E=16, depth 12): %.1f us per call" % ((time.perf_counter() - t0) / 100 * 1e6))
+qb = np.tile(q, (256, 1))
+for _ in range(3):
+    tdm.recommend(qb, 10, 20)
+t0 = time.perf_counter()
+for _ in range(20):
+    tdm.recommend(qb, 10, 20)
+print("256 users per call: %.1f us per call" % ((time.perf_counter() - t0) / 20 * 1e6))
