@@ -71,6 +71,10 @@ struct dm_ctx {
   int64_t last_rows = 0;
   // Deep-Retrieval model (dm_dr_load_model)
   dm_dr_state *dr = nullptr;
+  // request arena of the host-buffer entry points (grow only: no hipMalloc / hipFree on the request path)
+  void *d_req = nullptr;
+  size_t req_bytes = 0;
+  unsigned long long h_rows = 0;
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -273,7 +277,7 @@ int dm_destroy(dm_handle_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
-  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws);
+  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -815,15 +819,26 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
   int rc = DM_OK;
   const size_t nout = (size_t)U * opts->topk;
   do {
-    if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_ids, nout * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_scores, nout * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_counts, (size_t)U * 4)) != DM_OK) break;
+    // one arena for the request's device buffers, kept in the handle
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int64_t nc = coff ? coff[U] : 0;
+    const size_t b_seq = al((size_t)U * L * 4), b_out = al(nout * 4), b_cnt = al((size_t)U * 4);
+    const size_t b_coff = coff ? al((size_t)(U + 1) * 8) : 0, b_cids = coff ? al((size_t)(nc > 0 ? nc : 1) * 4) : 0;
+    const size_t need = b_seq + 2 * b_out + b_cnt + b_coff + b_cids;
+    if (h->req_bytes < need) {
+      dm_free_ptr(h->d_req); h->d_req = nullptr; h->req_bytes = 0;
+      if ((rc = dm_alloc(h, &h->d_req, need + need / 2)) != DM_OK) break;
+      h->req_bytes = need + need / 2;
+    }
+    char *base = (char *)h->d_req;
+    d_seq = (int32_t *)base; base += b_seq;
+    d_ids = (int32_t *)base; base += b_out;
+    d_scores = (float *)base; base += b_out;
+    d_counts = (int32_t *)base; base += b_cnt;
     if (hipMemcpyAsync(d_seq, seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
     if (coff) {
-      const int64_t nc = coff[U];
-      if ((rc = dm_alloc(h, (void **)&d_coff, (size_t)(U + 1) * 8)) != DM_OK) break;
-      if ((rc = dm_alloc(h, (void **)&d_cids, (size_t)(nc > 0 ? nc : 1) * 4)) != DM_OK) break;
+      d_coff = (int64_t *)base; base += b_coff;
+      d_cids = (int32_t *)base; base += b_cids;
       if (hipMemcpyAsync(d_coff, coff, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
       if (nc > 0 && hipMemcpyAsync(d_cids, cids, (size_t)nc * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
     }
@@ -846,13 +861,12 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
       if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, nt * cap * 4, hipMemcpyDeviceToHost, h->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream);
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h->h_rows, h->d_rows, 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("tdm beam search: ") + hipGetErrorString(e)); break; }
-    unsigned long long rows = 0;
-    if (hipMemcpy(&rows, h->d_rows, 8, hipMemcpyDeviceToHost) == hipSuccess) h->last_rows = (int64_t)rows;
+    h->last_rows = (int64_t)h->h_rows;
   } while (0);
-  dm_free_ptr(d_seq); dm_free_ptr(d_cids); dm_free_ptr(d_ids); dm_free_ptr(d_counts); dm_free_ptr(d_tc); dm_free_ptr(d_tn);
-  dm_free_ptr(d_coff); dm_free_ptr(d_scores); dm_free_ptr(d_ts);
+  dm_free_ptr(d_tc); dm_free_ptr(d_tn); dm_free_ptr(d_ts);      // trace buffers (parity instrumentation) are per call
   return rc;
 }
 
