@@ -23,3 +23,8 @@ t0 = time.perf_counter()
 for _ in range(20):
     tdm.recommend(qb, 10, 20)
 print("256 users per call: %.1f us per call" % ((time.perf_counter() - t0) / 20 * 1e6))
+eng.timing_reset()
+for _ in range(100):
+    tdm.recommend(q, 10, 20)
+n, ms = eng.timing_get()
+print("kernel time inside the single-user call: %.1f us (HIP events, %d launches)" % (ms / n * 1e3, n))
