@@ -237,6 +237,44 @@ def main():
             res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
         res_main = res
     default_cfg = (a.items, a.depth) == (10_000_000, 24)
+    # ---- extras on the SAME 10M-item engine: OTM serving (BASELINE configs[2], complete-tree variant of the level loop) and the
+    #      JTM re-assignment scoring step (configs[3]); host-buffer entry points, so these rates include the PCIe copies ----
+    otm = jtm = None
+    if a.small and default_cfg:
+        Uo = 32768
+        lut = np.zeros(int(tree["leaf_ids"].max()) + 1, np.int32)
+        lut[tree["leaf_ids"]] = tree["leaf_codes"]
+        ocodes = np.where(seqs[:Uo] > 0, lut[np.clip(seqs[:Uo], 0, lut.size - 1)], -1).astype(np.int32)   # items -> leaf nodes (OTM.scala:15)
+        eng.otm_beam_search(ocodes[:1024], a.beam, depth)
+        sync(); eng.timing_reset(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)
+        sync(); barrier()
+        dto = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        nlo, kmo = eng.timing_get()
+        otm = {"workload": "OTM beam-search serving on the same table: complete depth-%d tree, beam=%d, %d leaf-level candidates per user "
+                           "returned, host buffers (PCIe copies included)" % (depth, a.beam, 2 * a.beam),
+               "users_per_s": world * Uo * 2 / dto, "kernel_users_per_s": Uo * nlo / (kmo * 1e-3) if kmo > 0 else None,
+               "users_per_call": Uo}
+        # JTM: one gap step (levels 10 -> 12) of TreeLearning.aggregateWeights for a slice of items, 4 training rows each
+        from dismember_amd.jtm import JTM
+        ni_j = 50_000
+        jrng = np.random.default_rng(synth.SEED + 55 + rank)
+        jitems = tree["leaf_ids"][:ni_j]
+        jrows = {int(it): seqs[jrng.integers(0, a.users, 4)].reshape(-1) for it in jitems}
+        jt = JTM(eng, jitems, tree["leaf_codes"][:ni_j], depth, jrows, gap=2, seq_len=L)
+        node10 = JTM.ancestor_at_level(jt.item_code, 10)
+        jt.child_weights(node10[:], 10, 12)
+        sync(); barrier()
+        t0 = time.perf_counter()
+        wj = jt.child_weights(node10, 10, 12)
+        sync(); barrier()
+        dtj = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        jtm = {"workload": "JTM re-assignment scoring, one gap-2 step (levels 10 -> 12): %d items x 4 training rows x 6 chain nodes "
+                           "= %d DIN rows per worker; pairs expanded, scored and summed (reference-order fp32) on the device, host buffers in and out" % (ni_j, ni_j * 4 * 6),
+               "items_per_s": world * ni_j / dtj, "din_rows_per_s": world * ni_j * 24 / dtj, "ms": dtj * 1e3,
+               "finite_weights": bool(np.isfinite(wj).all())}
     # ---- extra: BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel training step on it ----
     small = train = None
     if a.small and default_cfg:
@@ -361,6 +399,10 @@ def main():
     if rank == 0:
         if dr is not None:
             res_main["extra_deep_retrieval"] = dr
+        if otm is not None:
+            res_main["extra_otm_serve"] = otm
+        if jtm is not None:
+            res_main["extra_jtm_scoring"] = jtm
         if small is not None:
             res_main["extra_1m_item_tree"] = small
         if train is not None:
