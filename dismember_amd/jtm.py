@@ -84,13 +84,9 @@ class JTM:
             w = (weight_fn or self.child_weights)(proj, old_level, level)
             old_node = self.ancestor_at_level(self.item_code, level)
             max_assign = 1 << (self.max_level - level)         # TreeLearning.scala:56
-            new = proj.copy()
-            order = np.argsort(proj, kind="stable")            # items of one node, ascending item id
-            bounds = np.flatnonzero(np.diff(proj[order])) + 1
-            for grp in np.split(order, bounds):
-                node = int(proj[grp[0]])
-                out = self.rebalance(w[grp], old_node[grp], node, old_level, level, max_assign)
-                keep = out >= 0
-                new[grp[keep]] = out[keep]                      # dropped items keep their old node (foldLeft(_ ++ _), :72)
+            w = np.ascontiguousarray(w, np.float32)
+            new = np.empty_like(proj)                          # every parent node of the level in one call
+            self.engine._chk(N.lib().dm_jtm_rebalance_all(self.engine._h, _p(w, N.f32p), _p(_i32(old_node), N.i32p), _p(proj, N.i32p),
+                                                          proj.size, old_level, level, int(max_assign), _p(new, N.i32p)))
             proj = new
         return dict(zip(self.items.tolist(), proj.tolist()))

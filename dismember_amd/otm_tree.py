@@ -75,12 +75,9 @@ class TreeConstruction:
             w = (weight_fn or self.child_weights)(proj, old_level, level)
             old_node = self.ancestor_at_level(self.item_leaf, level)
             max_assign = 1 << (self.leaf_level - level)
-            new = proj.copy()
-            order = np.argsort(proj, kind="stable")
-            bounds = np.flatnonzero(np.diff(proj[order])) + 1
-            for grp in np.split(order, bounds):
-                out = self.rebalance(w[grp], old_node[grp], int(proj[grp[0]]), old_level, level, max_assign)
-                keep = out >= 0
-                new[grp[keep]] = out[keep]
+            w = np.ascontiguousarray(w, np.float64)
+            new = np.empty_like(proj)
+            self.engine._chk(N.lib().dm_otm_rebalance_all(self.engine._h, w.ctypes.data_as(C.POINTER(C.c_double)), _p(_i32(old_node), N.i32p),
+                                                          _p(proj, N.i32p), proj.size, old_level, level, int(max_assign), _p(new, N.i32p)))
             proj = new
         return dict(zip(self.items.tolist(), proj.tolist()))

@@ -245,22 +245,10 @@ class JTM {
       e_.check(dm_jtm_child_weights(e_.handle(), rowOff_.data(), rowIds_.data(), proj.data(), (int64_t)n, L_, oldLevel, level,
                                     hier_ ? 1 : 0, minLevel_, useMask_ ? 1 : 0, w.data()));
       const int maxAssign = 1 << (maxLevel_ - level);              // TreeLearning.scala:56
-      std::map<int32_t, std::vector<size_t>> groups;               // items of one node, ascending item id
-      for (size_t i = 0; i < n; i++) groups[proj[i]].push_back(i);
-      std::vector<int32_t> next = proj;
-      for (auto &g : groups) {
-        const size_t m = g.second.size();
-        std::vector<float> gw(m * (size_t)nchild);
-        std::vector<int32_t> oldNode(m), out(m);
-        for (size_t k = 0; k < m; k++) {
-          std::copy(w.begin() + (ptrdiff_t)(g.second[k] * (size_t)nchild), w.begin() + (ptrdiff_t)((g.second[k] + 1) * (size_t)nchild),
-                    gw.begin() + (ptrdiff_t)(k * (size_t)nchild));
-          oldNode[k] = ancestorAtLevel(itemCode_[g.second[k]], level);
-        }
-        e_.check(dm_jtm_rebalance(e_.handle(), gw.data(), oldNode.data(), (int64_t)m, g.first, oldLevel, level, maxAssign, out.data()));
-        for (size_t k = 0; k < m; k++)
-          if (out[k] >= 0) next[g.second[k]] = out[k];            // dropped items keep their old node (:72)
-      }
+      std::vector<int32_t> oldNode(n), next(n);
+      for (size_t i = 0; i < n; i++) oldNode[i] = ancestorAtLevel(itemCode_[i], level);
+      // every parent node of the level in one call; dropped items keep their old node (:72)
+      e_.check(dm_jtm_rebalance_all(e_.handle(), w.data(), oldNode.data(), proj.data(), (int64_t)n, oldLevel, level, maxAssign, next.data()));
       proj.swap(next);
     }
     std::map<int32_t, int32_t> res;

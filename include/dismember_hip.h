@@ -149,6 +149,14 @@ int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *r
 int dm_jtm_rebalance(dm_handle_t h, const float *weights, const int32_t *old_node, int64_t n, int32_t node, int old_level,
                      int level, int max_assign, int32_t *out_node);
 
+/* The same for EVERY parent node of a level in one call (the loop over currentNodes of JTM.optimize, J/optim/JTM.scala:36-70;
+ * TreeConstruction.run, O/tree/TreeConstruction.scala:44-101): items are grouped by item_node [n] (the node each item sits in at
+ * old_level) in the order given; out_node [n] = the new child code, or the old node for items the greedy loop drops. */
+int dm_jtm_rebalance_all(dm_handle_t h, const float *weights, const int32_t *old_node, const int32_t *item_node, int64_t n,
+                         int old_level, int level, int max_assign, int32_t *out_node);
+int dm_otm_rebalance_all(dm_handle_t h, const double *weights, const int32_t *old_node, const int32_t *item_node, int64_t n,
+                         int old_level, int level, int max_assign, int32_t *out_node);
+
 /* OTM twin (otm/src/main/scala/com/mass/otm/tree/TreeConstruction.scala): the item sequences hold NODE ids (-1 =
  * paddingIdx, :218-232), the scorer runs in the loaded dtype (fp64 in the reference) and sums are double:
  * dm_otm_child_weights = aggregateWeights (:194-212) per child of getChildrenAtLevel (:281-285);
