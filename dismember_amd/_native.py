@@ -110,7 +110,7 @@ def build(force=False, verbose=False):
     srcs.append(os.path.join(INCLUDE_DIR, "dismember_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", LIB_PATH,
            os.path.join(SRC_DIR, "dm_hip.hip")]
     if verbose:
         print(" ".join(cmd))

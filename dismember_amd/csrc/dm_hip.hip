@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
