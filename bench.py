@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--small", type=int, default=1, help="also time BASELINE configs[1] (1M-item depth-20 tree) and the training step on it; 0 = skip")
     ap.add_argument("--big", type=int, default=None, help=argparse.SUPPRESS)   # old name of --small
     ap.add_argument("--dr", type=int, default=1, help="also time Deep-Retrieval serving (config 5: D=3, K=1000, beam=50, 10M items); 0 = skip")
+    ap.add_argument("--scorer", default="f32", choices=["f32", "split_f16"],
+                    help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode)")
+    ap.add_argument("--split", type=int, default=1, help="also time the split-fp16 scorer mode on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
     a = ap.parse_args()
     if a.big is not None:
@@ -153,6 +156,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    eng.set_scorer_mode(a.scorer)
     for _ in range(a.warmup):
         eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync()
@@ -172,6 +176,34 @@ def main():
     cnt = np.empty(U, np.int32)
     eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
 
+    # ---- extra: the same search with the other scorer arithmetic (same engine, same users) ----
+    split = None
+    if a.split and a.scorer == "f32" and E % 32 == 0:
+        eng.set_scorer_mode("split_f16")
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)     # builds the fp16 planes, warms up
+        sync(); eng.timing_reset(); barrier()
+        t0 = time.perf_counter()
+        n_split = max(2, a.steps // 2)
+        for _ in range(n_split):
+            eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync(); barrier()
+        dts = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        nls, kms = eng.timing_get()
+        ids_s = np.empty((U, a.topk), np.int32); sc_s = np.empty((U, a.topk), np.float32); cnt_s = np.empty(U, np.int32)
+        eng.d2h(ids_s, d_ids); eng.d2h(sc_s, d_sc); eng.d2h(cnt_s, d_cnt)
+        info = eng.scorer_mode()
+        eng.set_scorer_mode("f32")
+        same_rows = (ids_s == ids).all(axis=1) & (cnt_s == cnt)
+        dsc = np.abs(sc_s[same_rows].astype(np.float64) - sc[same_rows])
+        split = {"mode": "DM_SCORER_SPLIT_F16: q.k and W1a.q on the fp16 matrix pipe with fp32 operands split hi+lo (3 MFMAs per "
+                         "product, fp32 accumulation); same inputs, engine and beam logic as the headline run",
+                 "users_per_s": world * U * n_split / dts, "ms_per_step": dts / n_split * 1e3, "steps": n_split,
+                 "kernel_ms_avg": kms / max(nls, 1), "speedup_vs_f32_mode": (dt / a.steps) / (dts / n_split),
+                 "shift_emb": info["shift_emb"], "shift_w": info["shift_w"],
+                 "identical_id_lists_vs_f32_mode": "%d/%d" % (int(same_rows.sum()), U),
+                 "max_abs_score_diff_on_identical_lists": float(dsc.max()) if dsc.size else None,
+                 "max_abs_score": float(np.abs(sc).max())}
+
     if rank == 0:
         avg_ms = kernel_ms / max(n_launch, 1)
         kq = (L + 3) // 4
@@ -187,7 +219,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
+            "dtype": "f32" if a.scorer == "f32" else "f32 operands as fp16 hi+lo pairs, fp32 accumulation", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
             "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
                                    "beam=%d, topk=%d, L=%d, 1xMI355X per shard (the catalogue BASELINE.json's metric names; 17.2 GB table)"
                                    % (a.items, depth, E, a.beam, a.topk, L),
@@ -399,6 +431,8 @@ def main():
     if rank == 0:
         if dr is not None:
             res_main["extra_deep_retrieval"] = dr
+        if split is not None:
+            res_main["extra_split_f16_scorer"] = split
         if otm is not None:
             res_main["extra_otm_serve"] = otm
         if jtm is not None:

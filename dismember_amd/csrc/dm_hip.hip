@@ -54,6 +54,12 @@ struct dm_ctx {
   f32x4 *d_attA = nullptr, *d_w1aA = nullptr, *d_w1bA = nullptr;   // A-fragment order (rows kernel)
   float *d_b1 = nullptr, *d_w2 = nullptr;
   float b2 = 0.f;
+  // split-fp16 scorer (dm_set_scorer_mode): fp16 hi/lo planes of W1a and the power-of-two scales, rebuilt lazily
+  int scorer_mode = DM_SCORER_F32;
+  bool split_dirty = true;
+  void *d_wsplit = nullptr;
+  unsigned *d_maxabs = nullptr;
+  int sh_e = 0, sh_w = 0;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
   // training state (dm_train_init)
   bool train_ready = false;
@@ -266,6 +272,7 @@ static void free_weights(dm_ctx *h) {
   if (h->emb32_owned) dm_free_ptr(h->d_emb32);
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
+  dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
@@ -459,7 +466,7 @@ static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64
   int rc = upload_derived<T>(h, E, w + num_index * E);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->embed = E; h->num_index = num_index; h->w_loaded = true;
+  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
   return DM_OK;
 }
 
@@ -490,7 +497,7 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
   HIPCHK(h, hipMemcpy(t.data(), d_compact + num_index * E, (size_t)tail * 4, hipMemcpyDeviceToHost));
   int rc = upload_derived<float>(h, E, t.data());
   if (rc != DM_OK) return rc;
-  h->embed = E; h->num_index = num_index; h->w_loaded = true;
+  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
   return DM_OK;
 }
 
@@ -668,7 +675,7 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   const int kq = (L + 3) / 4;
   int nteams = 0;
   for (int cand = 4; cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq);
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, h->scorer_mode == DM_SCORER_SPLIT_F16 && h->embed % 32 == 0);
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
   if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (about 2*beam*28 bytes + weights must fit 160 KiB)");
@@ -701,37 +708,131 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
   return DM_OK;
 }
 
-template <int E, int KQ>
+template <int E, int KQ, bool SPLIT>
 static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
-  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
   hipEvent_t e0, e1;
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  hipLaunchKernelGGL((dm_beam_kernel<E, KQ>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+  hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
   return DM_OK;
 }
 
-template <int E>
+template <int E, bool SPLIT>
 static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
   switch ((p.L + 3) / 4) {
-    case 1: return launch_beam_EK<E, 1>(h, p, pl);
-    case 2: return launch_beam_EK<E, 2>(h, p, pl);
-    case 3: return launch_beam_EK<E, 3>(h, p, pl);
-    default: return launch_beam_EK<E, 4>(h, p, pl);
+    case 1: return launch_beam_EK<E, 1, SPLIT>(h, p, pl);
+    case 2: return launch_beam_EK<E, 2, SPLIT>(h, p, pl);
+    case 3: return launch_beam_EK<E, 3, SPLIT>(h, p, pl);
+    default: return launch_beam_EK<E, 4, SPLIT>(h, p, pl);
   }
 }
 
-static int launch_beam(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+// ---- split-fp16 scorer: scales and the fp16 planes of W1a -------------------------------------------------------
+__global__ void dm_maxabs_kernel(const float *x, int64_t n, unsigned *out) {
+  unsigned m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;      // |x| as an ordered integer (NaN / inf sort highest)
+    m = b > m ? b : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// planes[p][s][nt][lane][i], lane = (g, m): W1a[16nt + m][32s + 16(i>>2) + 4g + (i&3)] * 2^sh_w split into fp16 hi (p=0) and
+// lo (p=1); the column order is the one the beam kernel's gathered rows have inside a lane (two float4 per k-step)
+__global__ void dm_build_wsplit_kernel(const float *wfrag, int E, float scale, _Float16 *planes) {
+  const int NT = E / 16, NS = E / 32;
+  const int n = NS * NT * 64 * 8;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int i = t & 7, lane = (t >> 3) & 63, nt = (t >> 9) % NT, s = (t >> 9) / NT;
+    const int jc = 2 * s + (i >> 2);
+    const float x = wfrag[(((size_t)jc * NT + nt) * 64 + lane) * 4 + (i & 3)] * scale;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    planes[t] = hi;
+    planes[(size_t)n + t] = lo;
+  }
+}
+
+// power-of-two shift that puts max|x| into [2^13, 2^14): every scaled value and every rounding of it stays below the fp16
+// maximum, and fp16 subnormals only start 2^27 below the largest element
+static int split_shift(unsigned maxbits) {
+  if (maxbits == 0 || maxbits >= 0x7f800000u) return 0;
+  float m;
+  memcpy(&m, &maxbits, 4);
+  int e;
+  frexpf(m, &e);               // m = f * 2^e, f in [0.5, 1)
+  int sh = 14 - e;
+  if (sh > 40) sh = 40;
+  if (sh < -40) sh = -40;
+  return sh;
+}
+
+static int ensure_split(dm_ctx *h) {
+  if (!h->split_dirty && h->d_wsplit) return DM_OK;
+  const int E = h->embed;
+  if (E % 32 != 0) return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size that is a multiple of 32");
+  if (!h->d_wsplit) ALLOC(h, h->d_wsplit, (size_t)E * E * 4);
+  if (!h->d_maxabs) ALLOC(h, h->d_maxabs, 8);
+  HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, 8, h->stream));
+  hipLaunchKernelGGL(dm_maxabs_kernel, dim3(4096), dim3(256), 0, h->stream, h->d_emb32, h->num_index * (int64_t)E, h->d_maxabs);
+  hipLaunchKernelGGL(dm_maxabs_kernel, dim3(16), dim3(256), 0, h->stream, (const float *)h->d_wfrag, (int64_t)E * E, h->d_maxabs + 1);
+  HIPCHK(h, hipGetLastError());
+  unsigned mb[2];
+  HIPCHK(h, hipMemcpyAsync(mb, h->d_maxabs, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->sh_e = split_shift(mb[0]);
+  h->sh_w = split_shift(mb[1]);
+  hipLaunchKernelGGL(dm_build_wsplit_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->d_wfrag, E, ldexpf(1.0f, h->sh_w),
+                     (_Float16 *)h->d_wsplit);
+  HIPCHK(h, hipGetLastError());
+  h->split_dirty = false;
+  return DM_OK;
+}
+
+static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
+  // the brute-force recall oracle (mode 2) always scores with the fp32-input MFMA
+  if (h->scorer_mode == DM_SCORER_SPLIT_F16 && p.mode != 2) {
+    int rc = ensure_split(h);
+    if (rc != DM_OK) return rc;
+    p.wsplit = (const dm_h8 *)h->d_wsplit;
+    p.emb_scale = ldexpf(1.0f, h->sh_e); p.score_unscale = ldexpf(1.0f, -2 * h->sh_e);
+    p.acc_scale = ldexpf(1.0f, h->sh_e + h->sh_w); p.out_unscale = ldexpf(1.0f, -(h->sh_e + h->sh_w));
+    switch (h->embed) {
+      case 32: return launch_beam_E<32, true>(h, p, pl);
+      case 64: return launch_beam_E<64, true>(h, p, pl);
+      case 128: return launch_beam_E<128, true>(h, p, pl);
+    }
+    return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size of 32, 64 or 128");
+  }
   switch (h->embed) {
-    case 16: return launch_beam_E<16>(h, p, pl);
-    case 32: return launch_beam_E<32>(h, p, pl);
-    case 64: return launch_beam_E<64>(h, p, pl);
-    case 128: return launch_beam_E<128>(h, p, pl);
+    case 16: return launch_beam_E<16, false>(h, p, pl);
+    case 32: return launch_beam_E<32, false>(h, p, pl);
+    case 64: return launch_beam_E<64, false>(h, p, pl);
+    case 128: return launch_beam_E<128, false>(h, p, pl);
   }
   return fail(h, DM_ERR_UNSUPPORTED, "unsupported embed size");
+}
+
+int dm_set_scorer_mode(dm_handle_t h, int mode) {
+  if (!h) return DM_ERR_INVALID;
+  if (mode != DM_SCORER_F32 && mode != DM_SCORER_SPLIT_F16) return fail(h, DM_ERR_INVALID, "dm_set_scorer_mode: unknown mode");
+  if (mode == DM_SCORER_SPLIT_F16 && h->w_loaded && h->embed % 32 != 0)
+    return fail(h, DM_ERR_UNSUPPORTED, "dm_set_scorer_mode: the split-fp16 scorer needs an embedding size of 32, 64 or 128");
+  h->scorer_mode = mode;
+  return DM_OK;
+}
+
+int dm_get_scorer_mode(dm_handle_t h, int *mode, int *shift_emb, int *shift_w) {
+  if (!h || !mode) return DM_ERR_INVALID;
+  *mode = h->scorer_mode;
+  if (shift_emb) *shift_emb = h->sh_e;
+  if (shift_w) *shift_w = h->sh_w;
+  return DM_OK;
 }
 
 static void fill_common(dm_ctx *h, BeamParams &p) {

@@ -79,6 +79,20 @@ int dm_level_start(int candidate_num, int *start_code, int *level);
 int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact,
                         int64_t n_elems);
 
+/* Arithmetic of the beam-search scorer (dm_tdm_beam_search*, dm_otm_beam_search*; no reference counterpart: the
+ * reference's Linear / MatMul call MKL sgemm, S/tensor/TensorNumeric.scala:265-266).
+ *   DM_SCORER_F32        fp32-input MFMA for every product (default; what every parity figure in DESIGN.md is quoted on)
+ *   DM_SCORER_SPLIT_F16  the two products that read the gathered embedding rows (attention scores q.k and the W1a half of
+ *                        linear1) take each fp32 operand as hi + lo fp16 halves (22 significand bits, scaled by a power of
+ *                        two into the fp16 range) and run hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32
+ *                        accumulation: per-product relative error <= 3 * 2^-22, the size of fp32 summation-order noise
+ *                        over E terms.  E must be 32, 64 or 128.  Scores differ from the F32 mode within the same stated
+ *                        tolerance (rtol 1e-4 / atol 1e-5); ids are the exact beam search on those scores.
+ * dm_get_scorer_mode also reports the power-of-two shifts in use (after the first search). */
+enum { DM_SCORER_F32 = 0, DM_SCORER_SPLIT_F16 = 1 };
+int dm_set_scorer_mode(dm_handle_t h, int mode);
+int dm_get_scorer_mode(dm_handle_t h, int *mode, int *shift_emb, int *shift_w);
+
 /* ---- operator level: Module.forward(Table(items, seqs, masks)) ---------- */
 
 /* call sites: T/model/Recommender.scala:93-94, O/model/CandidateSearcher.scala:40-50,

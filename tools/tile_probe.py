@@ -11,6 +11,7 @@ seqs = synth.make_users(tree["leaf_ids"], U, 10, np.random.default_rng(1))
 eng = Engine(0)
 eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], 20); eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
 eng.load_weights_din_synthetic(128, (1 << 21) - 1, synth.SEED, tree_depth=20, rho=0.95)
+eng.set_scorer_mode(os.environ.get("DM_SCORER", "f32"))
 d_seq = eng.dev_alloc(U * 40); d_ids = eng.dev_alloc(U * 800); d_sc = eng.dev_alloc(U * 800); d_cnt = eng.dev_alloc(U * 4)
 eng.h2d(d_seq, seqs)
 out = (C.c_ulonglong * 16)()
