@@ -84,7 +84,8 @@ def test_split_vs_f32_mode_and_scaling(oracle, emb_gain, w_gain):
             # softmax turns an absolute error in the attention logits into a relative one in the weights: with the
             # 30x table the logits are ~900x larger, and so is the gap between ANY two fp32 evaluation orders
             tight = 2e-6 if emb_gain <= 1.0 else 1e-4
-            assert (d <= tight * np.abs(sc0[u, :cnt0[u]]) + tight / 20 * big).all(), (u, d.max())
+            # (a logit is a sum of terms as large as the largest logit that may cancel: the absolute part scales with it)
+            assert (d <= tight * np.abs(sc0[u, :cnt0[u]]) + tight / 4 * big).all(), (u, d.max())
     # and back: the fp32 mode is unaffected by having used the other one
     eng.set_scorer_mode("f32")
     ids2, sc2, cnt2 = eng.tdm_beam_search(seqs, 40, 40)
