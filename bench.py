@@ -22,6 +22,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_MFMA_F16_TFLOPS = 2516.6  # v_mfma_f32_16x16x32_f16: 16384 FLOP / 16 cycles / SIMD x 1024 SIMDs x 2.4 GHz (the guide's "~2.5 PF dense")
+
+
+def roofline(mode, rows, avg_ms, E, L):
+    """MFMA roofline of the beam kernel for one scorer arithmetic.  achieved = ALGORITHMIC flops of this formulation
+    (2(E^2 + 2LE + E) per scored row) / kernel time.  peak: fp32-input MFMA peak for the f32 mode; for the
+    split mode every product costs 3 fp16 MFMAs on padded 16x16x32 tiles, so the pipe's dense fp16 peak is scaled by
+    algorithmic / issued flops (the time the matrix pipe minimally needs per row is what bounds the kernel)."""
+    kq = (L + 3) // 4
+    nt = E // 16
+    flops_own = 2 * (E * E + 2 * L * E + E)
+    t = avg_ms * 1e-3
+    ach = rows * flops_own / t / 1e12
+    if mode == "f32":
+        issued = (nt * 4 + kq * nt + nt * 4 * nt) * 2048 / 16.0            # S^T + P x G (ceil(L/4) k-steps) + main chain, 16x16x4
+        peak = PEAK_MFMA_F32_TFLOPS
+        extra = {"mfma_issued_tflops": rows * issued / t / 1e12}
+    else:
+        ns = E // 32
+        issued = 3 * (ns + nt + ns * nt) * 16384 / 16.0                      # 3 x (S^T + P x G + main chain), 16x16x32
+        peak = PEAK_MFMA_F16_TFLOPS * flops_own / issued
+        extra = {"mfma_issued_tflops_f16": rows * issued / t / 1e12, "f16_dense_peak_tflops": PEAK_MFMA_F16_TFLOPS,
+                 "issued_per_algorithmic_flop": issued / flops_own,
+                 "peak_note": "fp16 dense peak x algorithmic/issued flops: 3 fp16 MFMAs per product (hi*hi + hi*lo + lo*hi) on 16x16x32 tiles"}
+    r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+         "kernel": "dm_beam_kernel<%d, %d, %s>" % (E, kq, "true" if mode != "f32" else "false"), "kernel_ms_avg": avg_ms,
+         "flops_per_row_algorithmic": flops_own}
+    r.update(extra)
+    return r
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -43,9 +72,9 @@ def parse():
     ap.add_argument("--small", type=int, default=1, help="also time BASELINE configs[1] (1M-item depth-20 tree) and the training step on it; 0 = skip")
     ap.add_argument("--big", type=int, default=None, help=argparse.SUPPRESS)   # old name of --small
     ap.add_argument("--dr", type=int, default=1, help="also time Deep-Retrieval serving (config 5: D=3, K=1000, beam=50, 10M items); 0 = skip")
-    ap.add_argument("--scorer", default="f32", choices=["f32", "split_f16"],
-                    help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode)")
-    ap.add_argument("--split", type=int, default=1, help="also time the split-fp16 scorer mode on the same engine and inputs (0 = skip)")
+    ap.add_argument("--scorer", default="auto", choices=["auto", "f32", "split_f16"],
+                    help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode; auto = the library default)")
+    ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
     a = ap.parse_args()
     if a.big is not None:
@@ -176,41 +205,45 @@ def main():
     cnt = np.empty(U, np.int32)
     eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
 
-    # ---- extra: the same search with the other scorer arithmetic (same engine, same users) ----
-    split = None
-    if a.split and a.scorer == "f32" and E % 32 == 0:
-        eng.set_scorer_mode("split_f16")
-        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)     # builds the fp16 planes, warms up
+    # ---- extra: the same search with the OTHER scorer arithmetic (same engine, same users) ----
+    mode = eng.scorer_mode()["mode"]            # arithmetic in effect for the headline run
+    info = eng.scorer_mode()
+    other = None
+    if a.other_scorer and E % 32 == 0:
+        omode = "f32" if mode == "split_f16" else "split_f16"
+        eng.set_scorer_mode(omode)
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)     # warms up (split: builds the fp16 planes)
         sync(); eng.timing_reset(); barrier()
         t0 = time.perf_counter()
-        n_split = max(2, a.steps // 2)
-        for _ in range(n_split):
+        n_o = max(2, a.steps // 2)
+        for _ in range(n_o):
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
-        dts = sharding.max_over_ranks(time.perf_counter() - t0, dist)
-        nls, kms = eng.timing_get()
-        ids_s = np.empty((U, a.topk), np.int32); sc_s = np.empty((U, a.topk), np.float32); cnt_s = np.empty(U, np.int32)
-        eng.d2h(ids_s, d_ids); eng.d2h(sc_s, d_sc); eng.d2h(cnt_s, d_cnt)
-        info = eng.scorer_mode()
-        eng.set_scorer_mode("f32")
-        same_rows = (ids_s == ids).all(axis=1) & (cnt_s == cnt)
-        dsc = np.abs(sc_s[same_rows].astype(np.float64) - sc[same_rows])
-        split = {"mode": "DM_SCORER_SPLIT_F16: q.k and W1a.q on the fp16 matrix pipe with fp32 operands split hi+lo (3 MFMAs per "
-                         "product, fp32 accumulation); same inputs, engine and beam logic as the headline run",
-                 "users_per_s": world * U * n_split / dts, "ms_per_step": dts / n_split * 1e3, "steps": n_split,
-                 "kernel_ms_avg": kms / max(nls, 1), "speedup_vs_f32_mode": (dt / a.steps) / (dts / n_split),
-                 "shift_emb": info["shift_emb"], "shift_w": info["shift_w"],
-                 "identical_id_lists_vs_f32_mode": "%d/%d" % (int(same_rows.sum()), U),
+        dto_ = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        nlo_, kmo_ = eng.timing_get()
+        ids_o = np.empty((U, a.topk), np.int32); sc_o = np.empty((U, a.topk), np.float32); cnt_o = np.empty(U, np.int32)
+        eng.d2h(ids_o, d_ids); eng.d2h(sc_o, d_sc); eng.d2h(cnt_o, d_cnt)
+        if omode == "split_f16":
+            info = eng.scorer_mode()
+        eng.set_scorer_mode(a.scorer)
+        same_rows = (ids_o == ids).all(axis=1) & (cnt_o == cnt)
+        dsc = np.abs(sc_o[same_rows].astype(np.float64) - sc[same_rows])
+        other = {"mode": omode, "what": "the same search (engine, users, beam logic) with the other scorer arithmetic "
+                                        "(include/dismember_hip.h: dm_set_scorer_mode)",
+                 "users_per_s": world * U * n_o / dto_, "ms_per_step": dto_ / n_o * 1e3, "steps": n_o,
+                 "roofline": roofline(omode, rows, kmo_ / max(nlo_, 1), E, L),
+                 "headline_speedup_over_this": (dto_ / n_o) / (dt / a.steps),
+                 "identical_id_lists_vs_headline": "%d/%d" % (int(same_rows.sum()), U),
                  "max_abs_score_diff_on_identical_lists": float(dsc.max()) if dsc.size else None,
                  "max_abs_score": float(np.abs(sc).max())}
 
     if rank == 0:
         avg_ms = kernel_ms / max(n_launch, 1)
-        kq = (L + 3) // 4
-        flops_own = 2 * (E * E + 2 * L * E + E)                     # this formulation, per scored row
         flops_ref = 2 * (2 * L * E + 3 * E * E + E)                 # SURVEY.md §8d, reference formulation
-        mfma_issued = ((E // 16) * 4 + kq * (E // 16) + (E // 16) * 4 * (E // 16)) * 2048 / 16.0   # S^T + P x G (ceil(L/4) k-steps) + main chain
-        ach = rows * flops_own / (avg_ms * 1e-3) / 1e12
+        roof = roofline(mode, rows, avg_ms, E, L)
+        roof.update({"launches": n_launch, "reference_formulation_flops_per_row": flops_ref,
+                     "reference_formulation_tflops": rows * flops_ref / (avg_ms * 1e-3) / 1e12,
+                     "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9})
         res = {
             "metric": "beam-search users/sec + recall@200 vs brute-force, 10M-item tree" if a.items == 10_000_000 else
                       "beam-search users/sec (TDM serve, %d-item depth-%d tree, %d-d, beam %d)" % (a.items, depth, E, a.beam),
@@ -219,31 +252,25 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.scorer == "f32" else "f32 operands as fp16 hi+lo pairs, fp32 accumulation", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
+            "dtype": "f32" if mode == "f32" else "f32 (operands as fp16 hi+lo pairs on the fp16 matrix pipe, fp32 accumulation)", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
             "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
                                    "beam=%d, topk=%d, L=%d, 1xMI355X per shard (the catalogue BASELINE.json's metric names; 17.2 GB table)"
                                    % (a.items, depth, E, a.beam, a.topk, L),
                        "users_per_step_per_gpu": U, "parallelism": "user-sharded x%d, replicated table" % world,
                        "scored_rows_per_user": rows / U},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
-                         "kernel": "dm_beam_kernel<128>", "kernel_ms_avg": avg_ms, "launches": n_launch,
-                         "flops_per_row_algorithmic": flops_own,
-                         "reference_formulation_flops_per_row": flops_ref,
-                         "reference_formulation_tflops": rows * flops_ref / (avg_ms * 1e-3) / 1e12,
-                         "mfma_issued_tflops": rows * mfma_issued / (avg_ms * 1e-3) / 1e12,
-                         "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9},
+            "roofline": roof,
+            "scorer": {"mode": mode, "shift_emb": info["shift_emb"], "shift_w": info["shift_w"]},
         }
         # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (tools/collect_profiles.sh), which
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01e_summary.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01f_summary.json" if mode != "f32" else "r01e_summary.json")))
             pw = prof["bench_line_under_profiler"]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01e_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                     "(separate passes), bytes per launch, FETCH x2 gfx950 correction")
+                res["roofline"]["traffic_source"] = ("profiles/r01%s_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                     "(separate passes), bytes per launch, FETCH x2 gfx950 correction") % ("f" if mode != "f32" else "e")
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         except Exception:
             pass
@@ -320,6 +347,7 @@ def main():
         eng.load_tree(tree2["codes"], tree2["ids"], tree2["is_leaf"], depth2)
         eng.load_id_maps(tree2["leaf_ids"], tree2["leaf_codes"])
         eng.load_weights_din_synthetic(E, ni2, synth.SEED, tree_depth=depth2, rho=a.rho)
+        eng.set_scorer_mode(a.scorer)
         d_seq = eng.dev_alloc(U * L * 4); d_ids = eng.dev_alloc(U * a.topk * 4)
         d_sc = eng.dev_alloc(U * a.topk * 4); d_cnt = eng.dev_alloc(U * 4)
         eng.h2d(d_seq, seqs2)
@@ -337,7 +365,8 @@ def main():
                              % (items2, depth2, E, a.beam, a.topk),
                  "users_per_s": world * U * nst / dt2, "steps": nst, "ms_per_step": dt2 / nst * 1e3,
                  "scored_rows_per_user": rows2 / U,
-                 "roofline_frac": rows2 * 2 * (E * E + 2 * L * E + E) / (kms2 / max(nl2, 1) * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS}
+                 "scorer": eng.scorer_mode()["mode"],
+                 "roofline_frac": roofline(eng.scorer_mode()["mode"], rows2, kms2 / max(nl2, 1), E, L)["frac"]}
         if rank == 0:
             ids2 = np.empty((U, a.topk), np.int32); cnt2 = np.empty(U, np.int32)
             eng.d2h(ids2, d_ids); eng.d2h(cnt2, d_cnt)
@@ -431,8 +460,8 @@ def main():
     if rank == 0:
         if dr is not None:
             res_main["extra_deep_retrieval"] = dr
-        if split is not None:
-            res_main["extra_split_f16_scorer"] = split
+        if other is not None:
+            res_main["extra_other_scorer"] = other
         if otm is not None:
             res_main["extra_otm_serve"] = otm
         if jtm is not None:

@@ -55,7 +55,7 @@ struct dm_ctx {
   float *d_b1 = nullptr, *d_w2 = nullptr;
   float b2 = 0.f;
   // split-fp16 scorer (dm_set_scorer_mode): fp16 hi/lo planes of W1a and the power-of-two scales, rebuilt lazily
-  int scorer_mode = DM_SCORER_F32;
+  int scorer_mode = DM_SCORER_AUTO;
   bool split_dirty = true;
   void *d_wsplit = nullptr;
   unsigned *d_maxabs = nullptr;
@@ -667,6 +667,11 @@ struct SearchPlan {
   int nteams, cap, pcap, grid, ws_cap, lds;
 };
 
+// the scorer arithmetic the beam kernels will use for this handle's model (dm_set_scorer_mode)
+static bool use_split(const dm_ctx *h) {
+  return (h->scorer_mode == DM_SCORER_SPLIT_F16 || h->scorer_mode == DM_SCORER_AUTO) && h->embed % 32 == 0;
+}
+
 static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, bool tdm, SearchPlan *pl) {
   int cap = ((2 * max_beam + 15) / 16) * 16;
   if (cap < 32) cap = 32;
@@ -675,7 +680,7 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   const int kq = (L + 3) / 4;
   int nteams = 0;
   for (int cand = 4; cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, h->scorer_mode == DM_SCORER_SPLIT_F16 && h->embed % 32 == 0);
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, use_split(h));
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
   if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (about 2*beam*28 bytes + weights must fit 160 KiB)");
@@ -796,7 +801,9 @@ static int ensure_split(dm_ctx *h) {
 
 static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
   // the brute-force recall oracle (mode 2) always scores with the fp32-input MFMA
-  if (h->scorer_mode == DM_SCORER_SPLIT_F16 && p.mode != 2) {
+  if (h->scorer_mode == DM_SCORER_SPLIT_F16 && h->embed % 32 != 0)
+    return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size of 32, 64 or 128");
+  if (use_split(h) && p.mode != 2) {
     int rc = ensure_split(h);
     if (rc != DM_OK) return rc;
     p.wsplit = (const dm_h8 *)h->d_wsplit;
@@ -820,16 +827,17 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
 
 int dm_set_scorer_mode(dm_handle_t h, int mode) {
   if (!h) return DM_ERR_INVALID;
-  if (mode != DM_SCORER_F32 && mode != DM_SCORER_SPLIT_F16) return fail(h, DM_ERR_INVALID, "dm_set_scorer_mode: unknown mode");
+  if (mode != DM_SCORER_F32 && mode != DM_SCORER_SPLIT_F16 && mode != DM_SCORER_AUTO) return fail(h, DM_ERR_INVALID, "dm_set_scorer_mode: unknown mode");
   if (mode == DM_SCORER_SPLIT_F16 && h->w_loaded && h->embed % 32 != 0)
     return fail(h, DM_ERR_UNSUPPORTED, "dm_set_scorer_mode: the split-fp16 scorer needs an embedding size of 32, 64 or 128");
   h->scorer_mode = mode;
   return DM_OK;
 }
 
-int dm_get_scorer_mode(dm_handle_t h, int *mode, int *shift_emb, int *shift_w) {
+int dm_get_scorer_mode(dm_handle_t h, int *mode, int *effective, int *shift_emb, int *shift_w) {
   if (!h || !mode) return DM_ERR_INVALID;
   *mode = h->scorer_mode;
+  if (effective) *effective = (h->w_loaded && use_split(h)) ? DM_SCORER_SPLIT_F16 : DM_SCORER_F32;
   if (shift_emb) *shift_emb = h->sh_e;
   if (shift_w) *shift_w = h->sh_w;
   return DM_OK;

@@ -381,18 +381,18 @@ class Engine:
     def synchronize(self):
         self._chk(N.lib().dm_synchronize(self._h))
 
-    SCORER_F32, SCORER_SPLIT_F16 = 0, 1
+    _SCORER = {"f32": 0, "split_f16": 1, "auto": 2}
 
     def set_scorer_mode(self, mode):
-        """Arithmetic of the beam-search scorer: "f32" (fp32-input MFMA, default) or "split_f16" (fp16 hi/lo operand
-        split on the fp16 matrix pipe, fp32 accumulation; include/dismember_hip.h)."""
-        m = {"f32": 0, "split_f16": 1}.get(mode, mode)
-        self._chk(N.lib().dm_set_scorer_mode(self._h, int(m)))
+        """Arithmetic of the beam-search scorer: "f32" (fp32-input MFMA), "split_f16" (fp16 hi/lo operand split on the
+        fp16 matrix pipe, fp32 accumulation) or "auto" (default: split_f16 where E allows); include/dismember_hip.h."""
+        self._chk(N.lib().dm_set_scorer_mode(self._h, int(self._SCORER.get(mode, mode))))
 
     def scorer_mode(self):
-        m, se, sw = C.c_int(0), C.c_int(0), C.c_int(0)
-        self._chk(N.lib().dm_get_scorer_mode(self._h, C.byref(m), C.byref(se), C.byref(sw)))
-        return {"mode": "split_f16" if m.value == 1 else "f32", "shift_emb": se.value, "shift_w": sw.value}
+        m, eff, se, sw = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(N.lib().dm_get_scorer_mode(self._h, C.byref(m), C.byref(eff), C.byref(se), C.byref(sw)))
+        names = {v: k for k, v in self._SCORER.items()}
+        return {"mode": names[eff.value], "setting": names[m.value], "shift_emb": se.value, "shift_w": sw.value}
 
     def timing_reset(self):
         self._chk(N.lib().dm_kernel_timing_reset(self._h))

@@ -65,6 +65,13 @@ class Engine {
     check(dm_load_weights_din(h_, DM_F64, embedSize, numIndex, compact.data(), (int64_t)compact.size()));
     embed_ = embedSize;
   }
+  // arithmetic of the beam-search scorer: DM_SCORER_AUTO (default), DM_SCORER_F32, DM_SCORER_SPLIT_F16 (dismember_hip.h)
+  void setScorerMode(int mode) { check(dm_set_scorer_mode(h_, mode)); }
+  int scorerModeInEffect() const {
+    int m = 0, eff = 0;
+    dm_get_scorer_mode(h_, &m, &eff, nullptr, nullptr);
+    return eff;
+  }
   int maxLevel() const { return maxLevel_; }
   int embedSize() const { return embed_; }
 

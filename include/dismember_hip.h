@@ -81,17 +81,21 @@ int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, cons
 
 /* Arithmetic of the beam-search scorer (dm_tdm_beam_search*, dm_otm_beam_search*; no reference counterpart: the
  * reference's Linear / MatMul call MKL sgemm, S/tensor/TensorNumeric.scala:265-266).
- *   DM_SCORER_F32        fp32-input MFMA for every product (default; what every parity figure in DESIGN.md is quoted on)
- *   DM_SCORER_SPLIT_F16  the two products that read the gathered embedding rows (attention scores q.k and the W1a half of
+ *   DM_SCORER_F32        fp32-input MFMA for every product.
+ *   DM_SCORER_SPLIT_F16  the three products of a scored row (attention scores q.k, the W1a half and the attention half of
  *                        linear1) take each fp32 operand as hi + lo fp16 halves (22 significand bits, scaled by a power of
  *                        two into the fp16 range) and run hi*hi + hi*lo + lo*hi on the fp16 matrix pipe with fp32
- *                        accumulation: per-product relative error <= 3 * 2^-22, the size of fp32 summation-order noise
- *                        over E terms.  E must be 32, 64 or 128.  Scores differ from the F32 mode within the same stated
- *                        tolerance (rtol 1e-4 / atol 1e-5); ids are the exact beam search on those scores.
- * dm_get_scorer_mode also reports the power-of-two shifts in use (after the first search). */
-enum { DM_SCORER_F32 = 0, DM_SCORER_SPLIT_F16 = 1 };
+ *                        accumulation: per-product relative error <= 3 * 2^-22, below the fp32 summation-order noise that
+ *                        separates any two fp32 implementations over E terms (measured: DESIGN.md).  E must be 32, 64 or
+ *                        128.  Same stated tolerance as the F32 mode (rtol 1e-4 / atol 1e-5 against the oracle); ids are
+ *                        the exact beam search on the scores produced.
+ *   DM_SCORER_AUTO       (default) SPLIT_F16 where the embedding size allows it, F32 otherwise (E = 16).
+ * The brute-force recall oracle (dm_tdm_bruteforce_topk) and every other entry point always use fp32 / fp64 arithmetic.
+ * dm_get_scorer_mode: the setting, the arithmetic in effect for the loaded model, and the power-of-two shifts in use
+ * (after the first search). */
+enum { DM_SCORER_F32 = 0, DM_SCORER_SPLIT_F16 = 1, DM_SCORER_AUTO = 2 };
 int dm_set_scorer_mode(dm_handle_t h, int mode);
-int dm_get_scorer_mode(dm_handle_t h, int *mode, int *shift_emb, int *shift_w);
+int dm_get_scorer_mode(dm_handle_t h, int *mode, int *effective, int *shift_emb, int *shift_w);
 
 /* ---- operator level: Module.forward(Table(items, seqs, masks)) ---------- */
 

@@ -202,9 +202,10 @@ def test_tdm_consumed_and_widened_beam(engine_fixture, oracle_tree, oracle_din32
         assert not (set(ids[u, :cnt[u]].tolist()) & set(consumed[u]))
 
 
+@pytest.mark.parametrize("scorer", ["f32", "auto"])    # auto = the split-fp16 arithmetic for these sizes (test_gpu_split_scorer.py)
 @pytest.mark.parametrize("E,depth,n_items,beam", [(128, 11, 1500, 50), (64, 9, 512, 16), (32, 8, 200, 100),
                                                   (128, 12, 4096, 200)])
-def test_tdm_trace_replay_synthetic(oracle, E, depth, n_items, beam):
+def test_tdm_trace_replay_synthetic(oracle, E, depth, n_items, beam, scorer):
     rng = np.random.default_rng(E * 1000 + depth)
     t = synthetic_tree(rng, depth, n_items)
     NI = (1 << (depth + 1)) - 1
@@ -212,6 +213,7 @@ def test_tdm_trace_replay_synthetic(oracle, E, depth, n_items, beam):
     otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
     odin = oracle.Din(w, E, 10, NI)
     eng = make_engine(t, w, E)
+    eng.set_scorer_mode(scorer)
     seqs = random_histories(rng, t["leaf_ids"], 23, 10)
     seqs[0] = 0
     replay_and_check(otree, odin, eng, seqs, beam, min(2 * beam, 200))

@@ -65,6 +65,8 @@ def test_split_vs_f32_mode_and_scaling(oracle, emb_gain, w_gain):
     t, otree, odin, eng, _ = problem(oracle, 128, 11, 1500, 5, emb_gain, w_gain)
     rng = np.random.default_rng(9)
     seqs = random_histories(rng, t["leaf_ids"], 256, 10)
+    assert eng.scorer_mode() == dict(eng.scorer_mode(), setting="auto", mode="split_f16")    # the default for E = 128
+    eng.set_scorer_mode("f32")
     ids0, sc0, cnt0 = eng.tdm_beam_search(seqs, 40, 40)
     eng.set_scorer_mode("split_f16")
     ids1, sc1, cnt1 = eng.tdm_beam_search(seqs, 40, 40)
@@ -124,6 +126,7 @@ def test_split_otm_mode(oracle):
     eng.load_weights_din(w, E, NI)
     seqs = rng.integers((1 << depth) - 1, NI, (64, 10)).astype(np.int32)
     seqs[rng.random(seqs.shape) < 0.2] = -1
+    eng.set_scorer_mode("f32")
     i0, s0, c0 = eng.otm_beam_search(seqs, 20, depth)
     eng.set_scorer_mode("split_f16")
     i1, s1, c1 = eng.otm_beam_search(seqs, 20, depth)
@@ -141,4 +144,4 @@ def test_split_needs_multiple_of_32(engine_fixture):
     with pytest.raises(DismemberError) as e:       # the bundled model has E = 16
         engine_fixture.set_scorer_mode("split_f16")
     assert e.value.code == -5                       # DM_ERR_UNSUPPORTED
-    assert engine_fixture.scorer_mode()["mode"] == "f32"
+    assert engine_fixture.scorer_mode()["mode"] == "f32" and engine_fixture.scorer_mode()["setting"] == "auto"
