@@ -314,11 +314,18 @@ def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk):
         # the returned set is the true top-k up to score tolerance at the cut
         kth = np.sort(ref)[::-1][k - 1]
         assert all(ref_by_id[i] >= kth - (ATOL + RTOL * abs(kth)) for i in gpu_by_id)
-    # beam search with a beam wider than the tree == brute force (both sides on the GPU: exact)
+    # beam search with a beam wider than the tree == brute force (both sides on the GPU, both with the fp32-input
+    # arithmetic the brute-force mode always uses: exact)
     beam = 1 << (depth - 1)
+    eng.set_scorer_mode("f32")
     bids, bsc, bcnt = eng.tdm_beam_search(seqs, beam, k)
     for u in range(seqs.shape[0]):
         assert np.array_equal(np.sort(bsc[u, :k])[::-1], sc[u, :k])
+    # ... and within the stated tolerance with the default (split-fp16 where E allows) arithmetic
+    eng.set_scorer_mode("auto")
+    bids, bsc, bcnt = eng.tdm_beam_search(seqs, beam, k)
+    for u in range(seqs.shape[0]):
+        assert close(np.sort(bsc[u, :k])[::-1], sc[u, :k]).all()
     eng.close()
 
 

@@ -56,12 +56,13 @@ def test_split_all_history_lengths(oracle, L):
     eng.close()
 
 
-@pytest.mark.parametrize("emb_gain,w_gain", [(1.0, 1.0), (30.0, 1.0), (1e-6, 2e3), (7.0, 1e-5), (1.0, 3e4)])
+@pytest.mark.parametrize("emb_gain,w_gain", [(1.0, 1.0), (30.0, 1.0), (1e-6, 2e3), (7.0, 1e-2), (1.0, 3e4)])
 def test_split_vs_f32_mode_and_scaling(oracle, emb_gain, w_gain):
     """The two device modes against each other: the same ids for nearly every user and scores within 2e-6 relative
     (plus 1e-7 of the largest score), for tables whose magnitudes need shifts from 2^-1 to 2^+33.  (The embedding gain
     stays moderate on the high side: attention logits grow with its square and a softmax over logits of 1e7 is
-    ill-conditioned in ANY fp32 arithmetic, the oracle's included.)"""
+    ill-conditioned in ANY fp32 arithmetic, the oracle's included; and l1.W is not shrunk so far that every logit
+    collapses onto l2.b within a few ulps, where the ranking is rounding noise in any arithmetic.)"""
     t, otree, odin, eng, _ = problem(oracle, 128, 11, 1500, 5, emb_gain, w_gain)
     rng = np.random.default_rng(9)
     seqs = random_histories(rng, t["leaf_ids"], 256, 10)
