@@ -30,8 +30,10 @@ def problem(oracle, E, depth, n_items, seed, emb_gain=1.0, w_gain=1.0):
     return t, otree, odin, eng, seqs
 
 
+# (128, 11, 1655, 249): 498 candidates -> a 512-slot frontier that leaves room for two teams of FOUR waves only, two of
+# which hold nothing but padding during the prune (regression: they must stay out of the LDS key exchange)
 @pytest.mark.parametrize("E,depth,n_items,beam", [(128, 11, 1500, 50), (64, 9, 512, 16), (32, 8, 200, 100),
-                                                  (128, 12, 4096, 200)])
+                                                  (128, 12, 4096, 200), (128, 11, 1655, 249)])
 def test_trace_replay_split(oracle, E, depth, n_items, beam):
     t, otree, odin, eng, seqs = problem(oracle, E, depth, n_items, E * 1000 + depth)
     eng.set_scorer_mode("split_f16")

@@ -29,6 +29,7 @@ for c in range(n_cfg):
     otree = po.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
     odin = po.Din(w, E, 10, NI)
     eng = make_engine(t, w, E)
+    eng.set_scorer_mode(os.environ.get("DM_SCORER", "auto"))
     seqs = random_histories(rng, t["leaf_ids"], U, 10, pad_prob=float(rng.random()) * 0.6, unknown_prob=0.05)
     try:
         replay_and_check(otree, odin, eng, seqs, beam, topk, use_mask=bool(rng.integers(0, 2)))
