@@ -436,7 +436,7 @@ def main():
         dtr = sharding.max_over_ranks(time.perf_counter() - t0, dist)
         # per user: 3 history GEMM rows of K x L*E (the only matrix work left) + (1 + 50 + 50) table-row sums of K
         table_bytes = (beam_d * 1 + beam_d * 2) * Kd * 4
-        dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x 2 paths, %d-d, f32 (reference computes in f64)"
+        dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x 2 paths, %d-d, f32 model, history GEMM in the split-fp16 arithmetic (reference computes in f64)"
                           % (Dd, Kd, beam_d, items_d, E),
               "beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
               "beam_search_kernel_ms_per_step": kms_b / nsd,
