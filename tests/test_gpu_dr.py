@@ -190,3 +190,26 @@ def test_errors():
     with pytest.raises(DismemberError) as e:
         eng.dr_load_path_items(np.array([[1, 2, 3], [1, 2, 3]], np.int32), [0, 1, 2], [4, 5])
     assert e.value.code == -1                           # duplicate path
+
+
+def test_split_history_gemm_vs_fp32_gemm():
+    """Float models with E % 32 == 0 run the history GEMM on the fp16 matrix pipe (hi + lo operand split, fp32 accumulation:
+    dm_set_scorer_mode).  Against the fp32-input GEMM of the same model: the same paths for (nearly) every
+    user, probabilities within 2e-5 relative; and against the fp64 oracle the usual f32 contract."""
+    K, D, L, E, beam, n = 200, 3, 10, 64, 30, 5000
+    eng, orc, w, rng = make(K, D, L, E, n, 17, np.float32, scale=0.1, with_paths=False)
+    seqs = histories(rng, 96, L, n)
+    eng.set_scorer_mode("f32")
+    p0, v0, c0 = eng.dr_beam_search(seqs, beam)
+    eng.set_scorer_mode("auto")
+    p1, v1, c1 = eng.dr_beam_search(seqs, beam)
+    assert np.array_equal(c0, c1)
+    same = 0
+    for u in range(len(seqs)):
+        if np.array_equal(p0[u], p1[u]):
+            same += 1
+            np.testing.assert_allclose(v1[u], v0[u], rtol=2e-5, atol=0)
+        for q in (0, beam - 1):
+            assert abs(path_prob(orc, seqs[u], p1[u, q]) - v1[u, q]) <= 1e-4 * v1[u, q] + 1e-30
+    assert same >= 0.95 * len(seqs), same
+    assert not np.array_equal(v0, v1)        # the two GEMMs really are different kernels
