@@ -178,3 +178,39 @@ def test_search_without_mask(oracle):
         order = np.argsort(-ref, kind="stable")[:10]
         assert (np.abs(bsc[u, :10] - ref[order]) <= ATOL + RTOL * np.abs(ref[order])).all()
     eng.close()
+
+
+def test_jtm_rebalance_all_threads_equal_single_thread():
+    """Near the root a level has a few very large parents: dm_jtm_rebalance_all gives each of them several host threads
+    (parallel candidate sort, runs + stable merges).  The result must be the single-threaded dm_jtm_rebalance's, bit for bit,
+    including crowded ties (weights drawn from 16 values)."""
+    import ctypes as C
+    from dismember_amd import Engine
+    from dismember_amd import _native as N
+    rng = np.random.default_rng(8)
+    eng = Engine(0)
+    for n_parents, n in ((1, 700_000), (3, 900_000)):
+        old_level, level = (0, 2) if n_parents == 1 else (2, 4)
+        nchild = 4
+        parents = np.arange((1 << old_level) - 1, (1 << old_level) - 1 + n_parents, dtype=np.int32)
+        item_node = parents[rng.integers(0, n_parents, n)].astype(np.int32)
+        w = rng.integers(0, 16, (n, nchild)).astype(np.float32) / 4.0
+        w[rng.random(n) < 0.01] = -1e6                                    # items without rows
+        first_child = (item_node.astype(np.int64) << 2) + 3
+        old_node = (first_child + rng.integers(0, nchild, n)).astype(np.int32)
+        max_assign = int(n / n_parents / nchild * 1.02)
+        out = np.empty(n, np.int32)
+        i32p, f32p = N.i32p, N.f32p
+        eng._chk(N.lib().dm_jtm_rebalance_all(eng._h, w.ctypes.data_as(f32p), old_node.ctypes.data_as(i32p),
+                                              item_node.ctypes.data_as(i32p), n, old_level, level, max_assign, out.ctypes.data_as(i32p)))
+        for pnode in parents:
+            sel = np.nonzero(item_node == pnode)[0]
+            ws = np.ascontiguousarray(w[sel]); on = np.ascontiguousarray(old_node[sel])
+            ref = np.empty(sel.size, np.int32)
+            eng._chk(N.lib().dm_jtm_rebalance(eng._h, ws.ctypes.data_as(f32p), on.ctypes.data_as(i32p), sel.size, int(pnode),
+                                              old_level, level, max_assign, ref.ctypes.data_as(i32p)))
+            ref = np.where(ref >= 0, ref, pnode)
+            assert np.array_equal(out[sel], ref), int(pnode)
+            counts = np.bincount(out[sel] - ((int(pnode) << 2) + 3), minlength=nchild)[:nchild]
+            assert counts.max() <= max_assign
+    eng.close()

@@ -37,5 +37,6 @@ for old_level in range(0, depth, 2):
                                           proj.size, old_level, level, 1 << (depth - level), new.ctypes.data_as(N.i32p)))
     t3 = time.perf_counter()
     tw += t1 - t0; tr += t3 - t2
+    print("  levels %2d -> %2d: scoring %.2f s, re-balance %.2f s (%d parent nodes)" % (old_level, level, t1 - t0, t3 - t2, np.unique(proj).size), flush=True)
     proj = new
 print("scoring %.2f s, re-balance %.2f s" % (tw, tr))
