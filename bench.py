@@ -305,17 +305,24 @@ def main():
         lut[tree["leaf_ids"]] = tree["leaf_codes"]
         ocodes = np.where(seqs[:Uo] > 0, lut[np.clip(seqs[:Uo], 0, lut.size - 1)], -1).astype(np.int32)   # items -> leaf nodes (OTM.scala:15)
         eng.otm_beam_search(ocodes[:1024], a.beam, depth)
+        d_os = eng.dev_alloc(Uo * L * 4); d_oi = eng.dev_alloc(Uo * 2 * a.beam * 4); d_osc = eng.dev_alloc(Uo * 2 * a.beam * 4); d_oc = eng.dev_alloc(Uo * 4)
+        eng.h2d(d_os, ocodes)
+        eng.otm_beam_search_dev(d_os, Uo, L, a.beam, depth, d_oi, d_osc, d_oc)
         sync(); eng.timing_reset(); barrier()
         t0 = time.perf_counter()
-        for _ in range(2):
-            oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)
+        for _ in range(3):
+            eng.otm_beam_search_dev(d_os, Uo, L, a.beam, depth, d_oi, d_osc, d_oc)
         sync(); barrier()
         dto = sharding.max_over_ranks(time.perf_counter() - t0, dist)
-        nlo, kmo = eng.timing_get()
+        t0 = time.perf_counter()
+        oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)      # host buffers: PCIe copies of 3.3 KB per user included
+        dth = time.perf_counter() - t0
+        for d_ in (d_os, d_oi, d_osc, d_oc):
+            eng.dev_free(d_)
         otm = {"workload": "OTM beam-search serving on the same table: complete depth-%d tree, beam=%d, %d leaf-level candidates per user "
-                           "returned, host buffers (PCIe copies included)" % (depth, a.beam, 2 * a.beam),
-               "users_per_s": world * Uo * 2 / dto, "kernel_users_per_s": Uo * nlo / (kmo * 1e-3) if kmo > 0 else None,
-               "users_per_call": Uo}
+                           "returned; request and results resident in HBM (dm_otm_beam_search_dev)" % (depth, a.beam, 2 * a.beam),
+               "users_per_s": world * Uo * 3 / dto, "host_buffer_users_per_s": Uo / dth, "users_per_call": Uo,
+               "scorer": eng.scorer_mode()["mode"]}
         # JTM: one gap step (levels 10 -> 12) of TreeLearning.aggregateWeights for a slice of items, 4 training rows each
         from dismember_amd.jtm import JTM
         ni_j = 50_000

@@ -998,70 +998,99 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
                          trace_codes, trace_scores, trace_counts);
 }
 
+// OTM search on device buffers: d_ids / d_scores [U][2*beam], d_counts [U]; optional level traces (device)
+static int otm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, int beam, int leaf_level, int32_t *d_ids,
+                          float *d_scores, int32_t *d_counts, int max_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn,
+                          const SearchPlan &pl) {
+  const int stride = 2 * beam;
+  int rc = ensure_ws(h, (size_t)pl.grid * pl.nteams * pl.ws_cap * 16);
+  if (rc != DM_OK) return rc;
+  HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * stride * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * stride * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
+  BeamParams p;
+  fill_common(h, p);
+  const size_t per = (size_t)pl.grid * pl.nteams * pl.ws_cap;
+  p.seq = d_seq; p.U = U; p.L = L; p.use_mask = 1; p.beam = beam; p.topk = stride; p.mode = 1; p.otm_leaf_level = leaf_level;
+  p.nteams = pl.nteams; p.cap = pl.cap; p.pcap = pl.pcap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
+  p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
+  p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
+  p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = d_tn ? max_levels : 0;
+  return launch_beam(h, p, pl);
+}
+
+static int otm_check(dm_ctx *h, int64_t U, int L, int beam, int leaf_level, const char *who) {
+  if (!h->w_loaded) return fail(h, DM_ERR_STATE, std::string(who) + ": weights not loaded");
+  if (U < 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
+    return fail(h, DM_ERR_INVALID, std::string(who) + ": bad arguments");
+  if ((((int64_t)1) << (leaf_level + 1)) - 1 > h->num_index) return fail(h, DM_ERR_INDEX, std::string(who) + ": leaf level exceeds the embedding table");
+  return DM_OK;
+}
+
+// device-resident request (serving loops that keep their batches in HBM; the counterpart of dm_tdm_beam_search_dev).
+// History codes outside the table are treated as padding by the kernel (the host entry point rejects them).
+int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U, int L, int beam, int leaf_level,
+                           int32_t *d_out_node_ids, float *d_out_scores, int32_t *d_out_counts) {
+  if (!h) return DM_ERR_INVALID;
+  int rc = otm_check(h, U, L, beam, leaf_level, "dm_otm_beam_search_dev");
+  if (rc != DM_OK) return rc;
+  if (U == 0) return DM_OK;
+  if (!d_seq_codes || !d_out_node_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_dev: NULL argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  int start, level;
+  level_start_int(beam, &start, &level);
+  SearchPlan pl;
+  if ((rc = plan_search(h, beam, U, L, leaf_level - level, false, &pl)) != DM_OK) return rc;
+  return otm_search_dev(h, d_seq_codes, U, L, beam, leaf_level, d_out_node_ids, d_out_scores, d_out_counts, 0, nullptr, nullptr, nullptr, pl);
+}
+
 static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                            int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels, int32_t *tc,
                            float *ts, int32_t *tn) {
-  if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_otm_beam_search: weights not loaded");
-  if (U == 0 && L > 0 && L <= DM_MAXL && beam > 0) return DM_OK;          // an empty batch is not an error
-  if (!seq_codes || !out_node_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
-    return fail(h, DM_ERR_INVALID, "dm_otm_beam_search: bad arguments");
-  if ((((int64_t)1) << (leaf_level + 1)) - 1 > h->num_index) return fail(h, DM_ERR_INDEX, "dm_otm_beam_search: leaf level exceeds the embedding table");
+  int rc = otm_check(h, U, L, beam, leaf_level, "dm_otm_beam_search");
+  if (rc != DM_OK) return rc;
+  if (U == 0) return DM_OK;          // an empty batch is not an error
+  if (!seq_codes || !out_node_ids || !out_scores || !out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search: bad arguments");
   for (int64_t i = 0; i < U * L; i++)
     if (seq_codes[i] != -1 && (seq_codes[i] < 0 || seq_codes[i] >= h->num_index)) return fail(h, DM_ERR_INDEX, "dm_otm_beam_search: history code outside the embedding table");
   HIPCHK(h, hipSetDevice(h->device));
   int start, level;
   level_start_int(beam, &start, &level);
   SearchPlan pl;
-  int rc = plan_search(h, beam, U, L, leaf_level - level, false, &pl);
-  if (rc != DM_OK) return rc;
-  const int stride = 2 * beam;
-  int32_t *d_seq = nullptr, *d_ids = nullptr, *d_counts = nullptr, *d_tc = nullptr, *d_tn = nullptr;
-  float *d_scores = nullptr, *d_ts = nullptr;
-  do {
-    if ((rc = ensure_ws(h, (size_t)pl.grid * pl.nteams * pl.ws_cap * 16)) != DM_OK) break;
-    if (tn) {
-      const size_t nt = (size_t)U * max_levels;
-      if ((rc = dm_alloc(h, (void **)&d_tc, nt * pl.cap * 4)) != DM_OK) break;
-      if ((rc = dm_alloc(h, (void **)&d_ts, nt * pl.cap * 4)) != DM_OK) break;
-      if ((rc = dm_alloc(h, (void **)&d_tn, nt * 4)) != DM_OK) break;
-      if (hipMemsetAsync(d_tn, 0, nt * 4, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "memset failed"); break; }
-    }
-    if ((rc = dm_alloc(h, (void **)&d_seq, (size_t)U * L * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_ids, (size_t)U * stride * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_scores, (size_t)U * stride * 4)) != DM_OK) break;
-    if ((rc = dm_alloc(h, (void **)&d_counts, (size_t)U * 4)) != DM_OK) break;
-    hipError_t e = hipMemcpyAsync(d_seq, seq_codes, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_ids, 0xFF, (size_t)U * stride * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_scores, 0, (size_t)U * stride * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_rows, 0, 16, h->stream);
-    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: upload failed"); break; }
-    BeamParams p;
-    fill_common(h, p);
-    const size_t per = (size_t)pl.grid * pl.nteams * pl.ws_cap;
-    p.seq = d_seq; p.U = U; p.L = L; p.use_mask = 1; p.beam = beam; p.topk = stride; p.mode = 1; p.otm_leaf_level = leaf_level;
-    p.nteams = pl.nteams; p.cap = pl.cap; p.pcap = pl.pcap; p.out_ids = d_ids; p.out_scores = d_scores; p.out_counts = d_counts; p.out_stride = stride;
-    p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
-    p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
-    p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = tn ? max_levels : 0;
-    if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
-    if (tn) {
-      const size_t nt = (size_t)U * max_levels;
-      e = hipMemcpyAsync(tc, d_tc, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream);
-      if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: trace download failed"); break; }
-    }
-    e = hipMemcpyAsync(out_node_ids, d_ids, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, (size_t)U * stride * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("dm_otm_beam_search: ") + hipGetErrorString(e)); break; }
-    unsigned long long rows = 0;
-    if (hipMemcpy(&rows, h->d_rows, 8, hipMemcpyDeviceToHost) == hipSuccess) h->last_rows = (int64_t)rows;
-  } while (0);
-  dm_free_ptr(d_seq); dm_free_ptr(d_ids); dm_free_ptr(d_scores); dm_free_ptr(d_counts); dm_free_ptr(d_tc); dm_free_ptr(d_ts); dm_free_ptr(d_tn);
-  return rc;
+  if ((rc = plan_search(h, beam, U, L, leaf_level - level, false, &pl)) != DM_OK) return rc;
+  const size_t stride = (size_t)2 * beam;
+  // request arena (grow only): no hipMalloc / hipFree on the request path
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t nt = tn ? (size_t)U * max_levels : 0;
+  const size_t o_seq = 0, o_ids = o_seq + up((size_t)U * L * 4), o_sc = o_ids + up(U * stride * 4), o_cnt = o_sc + up(U * stride * 4);
+  const size_t o_tc = o_cnt + up((size_t)U * 4), o_ts = o_tc + up(nt * pl.cap * 4), o_tn = o_ts + up(nt * pl.cap * 4);
+  const size_t need = o_tn + up(nt * 4);
+  if (h->req_bytes < need) {
+    dm_free_ptr(h->d_req); h->d_req = nullptr; h->req_bytes = 0;
+    if ((rc = dm_alloc(h, &h->d_req, need + need / 2)) != DM_OK) return rc;
+    h->req_bytes = need + need / 2;
+  }
+  char *base = (char *)h->d_req;
+  int32_t *d_seq = (int32_t *)(base + o_seq), *d_ids = (int32_t *)(base + o_ids), *d_counts = (int32_t *)(base + o_cnt);
+  float *d_scores = (float *)(base + o_sc);
+  int32_t *d_tc = tn ? (int32_t *)(base + o_tc) : nullptr, *d_tn = tn ? (int32_t *)(base + o_tn) : nullptr;
+  float *d_ts = tn ? (float *)(base + o_ts) : nullptr;
+  HIPCHK(h, hipMemcpyAsync(d_seq, seq_codes, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream));
+  if (tn) HIPCHK(h, hipMemsetAsync(d_tn, 0, nt * 4, h->stream));
+  if ((rc = otm_search_dev(h, d_seq, U, L, beam, leaf_level, d_ids, d_scores, d_counts, max_levels, d_tc, d_ts, d_tn, pl)) != DM_OK) return rc;
+  if (tn) {
+    HIPCHK(h, hipMemcpyAsync(tc, d_tc, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ts, d_ts, nt * pl.cap * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipMemcpyAsync(out_node_ids, d_ids, U * stride * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out_scores, d_scores, U * stride * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&h->h_rows, h->d_rows, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->last_rows = (int64_t)h->h_rows;
+  return DM_OK;
 }
 
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,

@@ -378,6 +378,9 @@ class Engine:
         self._chk(N.lib().dm_tdm_beam_search_dev(self._h, d_seq, U, L, C.byref(opts), None, None, d_ids, d_scores,
                                                  d_counts))
 
+    def otm_beam_search_dev(self, d_seq, U, L, beam, leaf_level, d_ids, d_scores, d_counts):
+        self._chk(N.lib().dm_otm_beam_search_dev(self._h, d_seq, U, L, int(beam), int(leaf_level), d_ids, d_scores, d_counts))
+
     def synchronize(self):
         self._chk(N.lib().dm_synchronize(self._h))
 

@@ -231,6 +231,10 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
                            const dm_tdm_search_opts *opts, const int64_t *d_consumed_off,
                            const int32_t *d_consumed_ids, int32_t *d_out_item_ids, float *d_out_scores,
                            int32_t *d_out_counts);
+/* OTM.recommend's search (dm_otm_beam_search) on a device-resident request: d_seq_codes [U][L] node ids (-1 = padding; codes
+ * outside the table count as padding), outputs [U][2*beam] leaf-level node ids (-1 filled) and scores, [U] counts. */
+int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U, int L, int beam, int leaf_level,
+                           int32_t *d_out_node_ids, float *d_out_scores, int32_t *d_out_counts);
 
 /* ---- Deep-Retrieval serving ----
  * D/ = deep-retrieval/src/main/scala/com/mass/dr/.  Item ids here are the INTERNAL ids of

@@ -214,3 +214,30 @@ def test_jtm_rebalance_all_threads_equal_single_thread():
             counts = np.bincount(out[sel] - ((int(pnode) << 2) + 3), minlength=nchild)[:nchild]
             assert counts.max() <= max_assign
     eng.close()
+
+
+def test_otm_device_resident_request_equals_host_path():
+    """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(21)
+    depth, E, L, beam, U = 9, 32, 7, 12, 50
+    NI = (1 << (depth + 1)) - 1
+    eng = Engine(0)
+    eng.load_weights_din(random_din_weights(rng, E, NI), E, NI)
+    seqs = rng.integers(0, NI, (U, L)).astype(np.int32)
+    seqs[rng.random(seqs.shape) < 0.3] = -1
+    ids, sc, cnt = eng.otm_beam_search(seqs, beam, depth)
+    d_s = eng.dev_alloc(seqs.nbytes); d_i = eng.dev_alloc(U * 2 * beam * 4); d_v = eng.dev_alloc(U * 2 * beam * 4); d_c = eng.dev_alloc(U * 4)
+    bad = seqs.copy()
+    bad[3, 2] = NI + 5                       # would be an index error on the host path; padding on the device path
+    ref_pad = seqs.copy(); ref_pad[3, 2] = -1
+    for src, want in ((seqs, (ids, sc, cnt)), (bad, eng.otm_beam_search(ref_pad, beam, depth))):
+        eng.h2d(d_s, src)
+        eng.otm_beam_search_dev(d_s, U, L, beam, depth, d_i, d_v, d_c)
+        eng.synchronize()
+        gi = np.empty((U, 2 * beam), np.int32); gv = np.empty((U, 2 * beam), np.float32); gc = np.empty(U, np.int32)
+        eng.d2h(gi, d_i); eng.d2h(gv, d_v); eng.d2h(gc, d_c)
+        assert np.array_equal(gi, want[0]) and np.array_equal(gv, want[1]) and np.array_equal(gc, want[2])
+    for d_ in (d_s, d_i, d_v, d_c):
+        eng.dev_free(d_)
+    eng.close()
