@@ -26,3 +26,6 @@ v = np.array(list(out)[:12], dtype=np.float64)
 names = ["setup: frontier init (+G/K frag write)", "P3 expand (+barrier)", "P4 scoring (own tiles)", "P4 tail wait (barrier)", "final select + user fetch", "user fetch barrier->setup(1)", "setup (1)-(2) seq+K gather", "setup (3)-(4) T1+G", "P1 + (no-sort path)", "P2 keygen", "P2 reg_sort", "P2 store + barrier"]
 print("kernel ms", eng.timing_get())
 for n, x in zip(names, v): print("%-28s %6.2f%%" % (n, 100 * x / v.sum()))
+n_waves = 256 * 8
+ms = eng.timing_get()[1] / max(eng.timing_get()[0], 1)
+print("shader clock under this kernel: %.3f GHz (sum of per-wave clock64 ticks / waves / kernel time)" % (v.sum() / n_waves / (ms * 1e-3) / 1e9))
