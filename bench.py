@@ -41,11 +41,11 @@ def roofline(mode, rows, avg_ms, E, L):
         extra = {"mfma_issued_tflops": rows * issued / t / 1e12}
     else:
         ns = E // 32
-        issued = 3 * (ns + nt + ns * nt) * 16384 / 16.0                      # 3 x (S^T + P x G + main chain), 16x16x32
+        issued = (3 * ns + 2 * nt + 3 * ns * nt) * 16384 / 16.0              # 3 x S^T + 2 x (P x G) + 3 x main chain, 16x16x32
         peak = PEAK_MFMA_F16_TFLOPS * flops_own / issued
         extra = {"mfma_issued_tflops_f16": rows * issued / t / 1e12, "f16_dense_peak_tflops": PEAK_MFMA_F16_TFLOPS,
                  "issued_per_algorithmic_flop": issued / flops_own,
-                 "peak_note": "fp16 dense peak x algorithmic/issued flops: 3 fp16 MFMAs per product (hi*hi + hi*lo + lo*hi) on 16x16x32 tiles"}
+                 "peak_note": "fp16 dense peak x algorithmic/issued flops: 3 fp16 MFMAs per product (hi*hi + hi*lo + lo*hi; 2 for the attention-combine product) on 16x16x32 tiles"}
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
          "kernel": "dm_beam_kernel<%d, %d, %s>" % (E, kq, "true" if mode != "f32" else "false"), "kernel_ms_avg": avg_ms,
          "flops_per_row_algorithmic": flops_own}
