@@ -464,9 +464,44 @@ def main():
             dr["cpu_baseline"] = {"value": len(cs) / dtc, "unit": "users/s", "cores": 1, "kind": "port",
                                   "sample": "%d users, fp64 oracle beam search (same D, K, beam, E, L; %d-item catalogue: the work per "
                                             "user does not depend on the catalogue size), 1 thread" % (len(cs), small_items)}
+    # ---- extra: BASELINE configs[0]'s own timer (examples/.../tdm/package.scala:119-123 prints "Average recommend time"): the bundled
+    #      trained E=16 model + tree, one user per call, topk 10, beam 20, 10 warm-up + 100 timed calls through the facade ----
+    c1 = None
+    if rank == 0 and a.small and default_cfg:
+        try:
+            from dismember_amd import TDM
+            from oracle import pyoracle as po
+            gdir = os.path.join(ROOT, "tests", "golden")
+            t1 = np.load(os.path.join(gdir, "tdm_tree.npz")); w1 = np.load(os.path.join(gdir, "din_f32.npy"))
+            e1 = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+            e1.load_tree(t1["codes"], t1["ids"], t1["is_leaf"], int(t1["max_level"])); e1.load_id_maps(t1["leaf_ids"], t1["leaf_codes"])
+            e1.load_weights_din(w1, 16, 8191)
+            q1 = np.array([0, 0, 2126, 204, 3257, 3439, 996, 1681, 3438, 1882], np.int32)      # the reference's example query
+            m1 = TDM(e1, "din")
+            for _ in range(10):
+                m1.recommend(q1, 10, 20)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                recs1 = m1.recommend(q1, 10, 20)
+            dt1 = (time.perf_counter() - t0) / 100
+            ot1 = po.TdmTree(t1["codes"], t1["ids"], t1["is_leaf"], t1["leaf_ids"], t1["leaf_codes"], t1["max_level"]); od1 = po.Din(w1, 16, 10, 8191)
+            ot1.recommend(od1, q1, 10, 20)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                oi1, _ol = ot1.recommend(od1, q1, 10, 20)
+            dto1 = (time.perf_counter() - t0) / 100
+            c1 = {"workload": "BASELINE configs[0] serving timer: bundled trained E=16 DIN + depth-12 tree (3706 items), TDM.recommend(query, topk=10, "
+                              "candidateNum=20), one user per call, 10 warm-up + 100 timed calls",
+                  "ms_per_call": dt1 * 1e3, "cpu_oracle_ms_per_call": dto1 * 1e3, "cpu_oracle": "oracle/libdm_oracle.so, 1 thread",
+                  "same_items_as_oracle": sorted(r_[0] for r_ in recs1) == sorted(oi1.tolist())}
+            e1.close()
+        except Exception as ex:       # the fixtures are test data: their absence must not break the bench line
+            c1 = {"skipped": repr(ex)}
     if rank == 0:
         if dr is not None:
             res_main["extra_deep_retrieval"] = dr
+        if c1 is not None:
+            res_main["extra_config0_latency"] = c1
         if other is not None:
             res_main["extra_other_scorer"] = other
         if otm is not None:
