@@ -145,10 +145,27 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
                        "reference path, one pthread per usable core (cgroup quota) over contiguous user ranges)" % (n_users, dt)), (ids, cnt)
 
 
+def init_distributed():
+    """The launcher contract (torchrun env): torch.distributed carries only the harness's barrier; the product's own
+    exchange (gradients, result gathers, the slowest-rank clock) runs over dismember_amd.comm (RCCL inside the library)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, None, rank, world, local
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from dismember_amd.comm import Comm
+    comm = Comm.from_env(transport=os.environ.get("DM_COMM_TRANSPORT", "rccl"), device_id=int(os.environ.get("DM_FORCE_DEVICE", local)))
+    return dist, comm, rank, world, local
+
+
 def main():
     a = parse()
     from dismember_amd import sharding
-    dist, rank, world, local = sharding.init_distributed()
+    dist, comm, rank, world, local = init_distributed()
     torch = None
     if dist is not None:
         import torch
@@ -196,7 +213,7 @@ def main():
         eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync(); barrier()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, dist)
+    dt = sharding.max_over_ranks(dt, comm)
     n_launch, kernel_ms = eng.timing_get()
     rows = eng.last_scored_rows()                    # scored (node, user) rows of ONE step
 
@@ -219,7 +236,7 @@ def main():
         for _ in range(n_o):
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
-        dto_ = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dto_ = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         nlo_, kmo_ = eng.timing_get()
         ids_o = np.empty((U, a.topk), np.int32); sc_o = np.empty((U, a.topk), np.float32); cnt_o = np.empty(U, np.int32)
         eng.d2h(ids_o, d_ids); eng.d2h(sc_o, d_sc); eng.d2h(cnt_o, d_cnt)
@@ -313,7 +330,7 @@ def main():
         for _ in range(3):
             eng.otm_beam_search_dev(d_os, Uo, L, a.beam, depth, d_oi, d_osc, d_oc)
         sync(); barrier()
-        dto = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dto = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         t0 = time.perf_counter()
         oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)      # host buffers: PCIe copies of 3.3 KB per user included
         dth = time.perf_counter() - t0
@@ -336,7 +353,7 @@ def main():
         t0 = time.perf_counter()
         wj = jt.child_weights(node10, 10, 12)
         sync(); barrier()
-        dtj = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dtj = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         jtm = {"workload": "JTM re-assignment scoring, one gap-2 step (levels 10 -> 12): %d items x 4 training rows x 6 chain nodes "
                            "= %d DIN rows per worker; pairs expanded, scored and summed (reference-order fp32) on the device, host buffers in and out" % (ni_j, ni_j * 4 * 6),
                "items_per_s": world * ni_j / dtj, "din_rows_per_s": world * ni_j * 24 / dtj, "ms": dtj * 1e3,
@@ -365,7 +382,7 @@ def main():
         for _ in range(nst):
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
-        dt2 = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dt2 = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         nl2, kms2 = eng.timing_get()
         rows2 = eng.last_scored_rows()
         small = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (BASELINE.json configs[1])"
@@ -394,7 +411,7 @@ def main():
             neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 19, 22, 25, 30], np.int32)   # configs/tdm.conf
             per = int(sum(1 + neg[l] for l in range(1, depth2 + 1)))
             Tt = max(1, 8192 // per)                        # total_batch_size 8192 expanded rows per worker
-            tr = TDMTrainer(eng, neg, lr=1e-4, dist=dist, torch=torch, seed=synth.SEED)
+            tr = TDMTrainer(eng, neg, lr=1e-4, comm=comm, seed=synth.SEED, sampler="host")
             trng = np.random.default_rng(synth.SEED + 7 + rank)
             tseq = synth.make_users(tree2["leaf_ids"], Tt, L, trng)
             ttgt = trng.choice(tree2["leaf_ids"], Tt).astype(np.int32)
@@ -405,7 +422,7 @@ def main():
             for _ in range(nts):
                 tloss = tr.step(tseq, ttgt)
             sync(); barrier()
-            dtt = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+            dtt = sharding.max_over_ranks(time.perf_counter() - t0, comm)
             nparam = ni2 * E + 3 * E * E + 2 * E + 1
             train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives), "
                                  "DIN fwd+bwd, gradient exchange, dense Adam over %d parameters" % (Tt, Tt * per, nparam),
@@ -432,7 +449,7 @@ def main():
         for _ in range(nsd):
             eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
         sync(); barrier()
-        dtb = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dtb = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         _, kms_b = eng.timing_get()
         eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
         sync(); barrier(); sync()
@@ -440,7 +457,7 @@ def main():
         for _ in range(nsd):
             eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
         sync(); barrier()
-        dtr = sharding.max_over_ranks(time.perf_counter() - t0, dist)
+        dtr = sharding.max_over_ranks(time.perf_counter() - t0, comm)
         # per user: 3 history GEMM rows of K x L*E (the only matrix work left) + (1 + 50 + 50) table-row sums of K
         table_bytes = (beam_d * 1 + beam_d * 2) * Kd * 4
         dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x 2 paths, %d-d, f32 model, history GEMM in the split-fp16 arithmetic (reference computes in f64)"
@@ -517,6 +534,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":

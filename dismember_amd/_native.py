@@ -97,6 +97,23 @@ SIGNATURES = {
     "dm_load_weights_din_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "dm_set_scorer_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dm_get_scorer_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dm_otm_beam_search_f64": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double), i32p]),
+    "dm_otm_beam_search_trace_f64": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double), i32p,
+                                               C.c_int, i32p, C.POINTER(C.c_double), i32p]),
+    "dm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dm_comm_create_rccl": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "dm_comm_create_tcp": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dm_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "dm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dm_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "dm_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dm_comm_barrier": (C.c_int, [C.c_void_p]),
+    "dm_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "dm_comm_all_gather_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "dm_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dm_comm_all_gather_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "dm_train_sync_gradients": (C.c_int, [C.c_void_p]),
+    "dm_allreduce_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
     "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dm_last_scored_rows": (C.c_int, [C.c_void_p, i64p]),
@@ -113,8 +130,10 @@ def build(force=False, verbose=False):
     srcs.append(os.path.join(INCLUDE_DIR, "dismember_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", LIB_PATH,
-           os.path.join(SRC_DIR, "dm_hip.hip")]
+           os.path.join(SRC_DIR, "dm_hip.hip"), "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"),
+           "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cerrno>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -70,7 +71,7 @@ struct dm_ctx {
   unsigned *d_touch_bits = nullptr;
   int32_t *d_touch_list = nullptr;
   unsigned long long *d_touch_cnt = nullptr;
-  size_t touch_cap = 0;
+  size_t touch_cap = 0, touch_ub = 0;   // list capacity; host-side upper bound of its length since the last Adam step
   // measurement
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -86,6 +87,10 @@ struct dm_ctx {
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
+  // multi-GPU exchange (comm.hip.inc): the attached communicator (not owned) and the staging area of dm_train_sync_gradients
+  struct dm_comm *comm = nullptr;
+  void *d_sync = nullptr;
+  size_t sync_bytes = 0;
 };
 
 static std::string g_create_err;
@@ -277,7 +282,7 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
   h->d_grad = h->d_adam_s = h->d_adam_r = h->d_loss = nullptr; h->d_attTA = h->d_w1aTA = h->d_w1bTA = nullptr;
-  h->d_touch_bits = nullptr; h->d_touch_list = nullptr; h->d_touch_cnt = nullptr; h->train_ready = false; h->touch_cap = 0;
+  h->d_touch_bits = nullptr; h->d_touch_list = nullptr; h->d_touch_cnt = nullptr; h->train_ready = false; h->touch_cap = 0; h->touch_ub = 0;
   h->d_afrag = h->d_bfrag = nullptr; h->d_attA = h->d_w1aA = h->d_w1bA = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
 }
 
@@ -286,7 +291,7 @@ int dm_destroy(dm_handle_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
-  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req);
+  dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -640,9 +645,12 @@ int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, con
   unsigned *d_mask = nullptr;
   void *d_out = nullptr;
   const size_t esz = h->dtype == DM_F32 ? 4 : 8;
-  ALLOC(h, d_codes, B * 4); ALLOC(h, d_seqs, B * L * 4); ALLOC(h, d_mask, B * 4); ALLOC(h, d_out, B * esz);
   int rc = DM_OK;
   do {
+    if ((rc = dm_alloc(h, (void **)&d_codes, B * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_seqs, B * L * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, (void **)&d_mask, B * 4)) != DM_OK) break;
+    if ((rc = dm_alloc(h, &d_out, B * esz)) != DM_OK) break;
     if (hipMemcpyAsync(d_codes, codes, B * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipMemcpyAsync(d_seqs, seqs, B * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipMemsetAsync(d_mask, 0, B * 4, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "dm_din_forward: upload failed"); break; }
@@ -670,6 +678,11 @@ struct SearchPlan {
 // the scorer arithmetic the beam kernels will use for this handle's model (dm_set_scorer_mode)
 static bool use_split(const dm_ctx *h) {
   return (h->scorer_mode == DM_SCORER_SPLIT_F16 || h->scorer_mode == DM_SCORER_AUTO) && h->embed % 32 == 0;
+}
+
+// fp64 parity mode of the OTM search (otm64.hip.inc): in effect when f64 weights are loaded and the scorer mode is AUTO or F64
+static bool use_f64_beam(const dm_ctx *h) {
+  return h->dtype == DM_F64 && (h->scorer_mode == DM_SCORER_AUTO || h->scorer_mode == DM_SCORER_F64);
 }
 
 static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, bool tdm, SearchPlan *pl) {
@@ -827,7 +840,9 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
 
 int dm_set_scorer_mode(dm_handle_t h, int mode) {
   if (!h) return DM_ERR_INVALID;
-  if (mode != DM_SCORER_F32 && mode != DM_SCORER_SPLIT_F16 && mode != DM_SCORER_AUTO) return fail(h, DM_ERR_INVALID, "dm_set_scorer_mode: unknown mode");
+  if (mode != DM_SCORER_F32 && mode != DM_SCORER_SPLIT_F16 && mode != DM_SCORER_AUTO && mode != DM_SCORER_F64) return fail(h, DM_ERR_INVALID, "dm_set_scorer_mode: unknown mode");
+  if (mode == DM_SCORER_F64 && h->w_loaded && h->dtype != DM_F64)
+    return fail(h, DM_ERR_UNSUPPORTED, "dm_set_scorer_mode: the fp64 scorer needs f64 weights");
   if (mode == DM_SCORER_SPLIT_F16 && h->w_loaded && h->embed % 32 != 0)
     return fail(h, DM_ERR_UNSUPPORTED, "dm_set_scorer_mode: the split-fp16 scorer needs an embedding size of 32, 64 or 128");
   h->scorer_mode = mode;
@@ -837,7 +852,7 @@ int dm_set_scorer_mode(dm_handle_t h, int mode) {
 int dm_get_scorer_mode(dm_handle_t h, int *mode, int *effective, int *shift_emb, int *shift_w) {
   if (!h || !mode) return DM_ERR_INVALID;
   *mode = h->scorer_mode;
-  if (effective) *effective = (h->w_loaded && use_split(h)) ? DM_SCORER_SPLIT_F16 : DM_SCORER_F32;
+  if (effective) *effective = (h->w_loaded && use_f64_beam(h)) ? DM_SCORER_F64 : (h->w_loaded && use_split(h)) ? DM_SCORER_SPLIT_F16 : DM_SCORER_F32;
   if (shift_emb) *shift_emb = h->sh_e;
   if (shift_w) *shift_w = h->sh_w;
   return DM_OK;
@@ -998,6 +1013,13 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
                          trace_codes, trace_scores, trace_counts);
 }
 
+static int otm64_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, int beam, int leaf_level, int32_t *d_ids,
+                            double *d_sc64, float *d_sc32, int32_t *d_counts, int max_levels, int cap, int32_t *d_tc,
+                            double *d_ts64, float *d_ts32, int32_t *d_tn);
+static int otm64_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                             int32_t *out_node_ids, double *out_sc64, float *out_sc32, int32_t *out_counts, int max_levels,
+                             int32_t *tc, double *ts64, float *ts32, int32_t *tn);
+
 // OTM search on device buffers: d_ids / d_scores [U][2*beam], d_counts [U]; optional level traces (device)
 static int otm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, int beam, int leaf_level, int32_t *d_ids,
                           float *d_scores, int32_t *d_counts, int max_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn,
@@ -1038,6 +1060,12 @@ int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U,
   if (U == 0) return DM_OK;
   if (!d_seq_codes || !d_out_node_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
+  if (use_f64_beam(h)) {
+    HIPCHK(h, hipMemsetAsync(d_out_node_ids, 0xFF, (size_t)U * 2 * beam * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_out_scores, 0, (size_t)U * 2 * beam * 4, h->stream));
+    return otm64_search_dev(h, d_seq_codes, U, L, beam, leaf_level, d_out_node_ids, nullptr, d_out_scores, d_out_counts, 0, 0, nullptr,
+                            nullptr, nullptr, nullptr);
+  }
   int start, level;
   level_start_int(beam, &start, &level);
   SearchPlan pl;
@@ -1096,6 +1124,8 @@ static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
+  if (use_f64_beam(h))      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
+    return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, 0, nullptr, nullptr, nullptr, nullptr);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, 0, nullptr, nullptr, nullptr);
 }
 
@@ -1104,6 +1134,9 @@ int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U,
                              int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
   if (!h) return DM_ERR_INVALID;
   if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_trace: bad trace arguments");
+  if (use_f64_beam(h))
+    return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, max_levels, trace_codes,
+                             nullptr, trace_scores, trace_counts);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, max_levels, trace_codes,
                          trace_scores, trace_counts);
 }
@@ -1197,6 +1230,8 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "jtm_host.hip.inc"
 #include "train_host.hip.inc"
 #include "dr_host.hip.inc"
+#include "otm64.hip.inc"
+#include "comm.hip.inc"
 
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {

@@ -187,6 +187,45 @@ class Engine:
                                              _p(sc, N.f32p), _p(cnt, N.i32p)))
         return ids, sc, cnt
 
+    def otm_beam_search_f64(self, seq_codes, beam, leaf_level, trace_levels=None):
+        """CandidateSearcher.beamSearch in the reference's own arithmetic (DIN[Double]); f64 weights required.  With
+        trace_levels: also every level's candidates (OTMTree.beamSearchNodes): (ids, scores, counts, tc, ts, tn)."""
+        seq = _i32(seq_codes)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        f64p = C.POINTER(C.c_double)
+        ids = np.empty((U, 2 * beam), np.int32)
+        sc = np.empty((U, 2 * beam), np.float64)
+        cnt = np.empty(U, np.int32)
+        if trace_levels is None:
+            self._chk(N.lib().dm_otm_beam_search_f64(self._h, _p(seq, N.i32p), U, L, int(beam), int(leaf_level), _p(ids, N.i32p),
+                                                     sc.ctypes.data_as(f64p), _p(cnt, N.i32p)))
+            return ids, sc, cnt
+        cap = max(32, ((2 * beam + 15) // 16) * 16)
+        tc = np.zeros((U, trace_levels, cap), np.int32)
+        ts = np.zeros((U, trace_levels, cap), np.float64)
+        tn = np.zeros((U, trace_levels), np.int32)
+        self._chk(N.lib().dm_otm_beam_search_trace_f64(self._h, _p(seq, N.i32p), U, L, int(beam), int(leaf_level), _p(ids, N.i32p),
+                                                       sc.ctypes.data_as(f64p), _p(cnt, N.i32p), int(trace_levels),
+                                                       _p(tc, N.i32p), ts.ctypes.data_as(f64p), _p(tn, N.i32p)))
+        return ids, sc, cnt, tc, ts, tn
+
+    def otm_beam_search_trace(self, seq_codes, beam, leaf_level, trace_levels):
+        """dm_otm_beam_search_trace (float scores; arithmetic per the scorer mode): (ids, scores, counts, tc, ts, tn)."""
+        seq = _i32(seq_codes)
+        if seq.ndim == 1:
+            seq = seq[None, :]
+        U, L = seq.shape
+        cap = max(32, ((2 * beam + 15) // 16) * 16)
+        ids = np.empty((U, 2 * beam), np.int32); sc = np.empty((U, 2 * beam), np.float32); cnt = np.empty(U, np.int32)
+        tc = np.zeros((U, trace_levels, cap), np.int32); ts = np.zeros((U, trace_levels, cap), np.float32)
+        tn = np.zeros((U, trace_levels), np.int32)
+        self._chk(N.lib().dm_otm_beam_search_trace(self._h, _p(seq, N.i32p), U, L, int(beam), int(leaf_level), _p(ids, N.i32p),
+                                                   _p(sc, N.f32p), _p(cnt, N.i32p), int(trace_levels), _p(tc, N.i32p),
+                                                   _p(ts, N.f32p), _p(tn, N.i32p)))
+        return ids, sc, cnt, tc, ts, tn
+
     def tdm_bruteforce_topk(self, seq_item_ids, topk, use_mask=True):
         seq = _i32(seq_item_ids)
         if seq.ndim == 1:
@@ -242,6 +281,33 @@ class Engine:
         """Row bit masks -> the flat index list Module.forward takes (Mask.scala:27-32)."""
         i, j = np.nonzero((mask[:, None] >> np.arange(L, dtype=np.uint32)[None, :]) & 1)
         return (i * L + j).astype(np.int32)
+
+    # ---- multi-GPU exchange (comm.py)
+    def attach_comm(self, comm):
+        """comm: dismember_amd.comm.Comm, a raw dm_comm_t (comm.make_clique) or None."""
+        self._comm = comm
+        self._chk(N.lib().dm_comm_attach(self._h, None if comm is None else getattr(comm, "_c", comm)))
+
+    def train_sync_gradients(self):
+        """LocalOptimizer.syncGradients over the attached communicator (collective: every rank calls it)."""
+        self._chk(N.lib().dm_train_sync_gradients(self._h))
+
+    def comm_all_gather_dev(self, arr):
+        """Var-size all-gather of DEVICE buffers over the attached communicator (dm_comm_all_gather_dev): uploads `arr`,
+        gathers on the handle's stream (RCCL broadcasts, or host staging on the host transport), returns the concatenation."""
+        a = np.ascontiguousarray(arr)
+        world = self._comm.world if hasattr(self._comm, "world") else 1
+        sizes = (C.c_uint64 * world)()
+        d_send = self.dev_alloc(max(a.nbytes, 16))
+        self.h2d(d_send, a)
+        self._chk(N.lib().dm_comm_all_gather_dev(self._h, d_send, a.nbytes, None, 0, sizes))
+        total = int(sum(sizes))
+        d_recv = self.dev_alloc(max(total, 16))
+        self._chk(N.lib().dm_comm_all_gather_dev(self._h, d_send, a.nbytes, d_recv, total, sizes))
+        out = np.empty(total // a.itemsize, a.dtype)
+        self.d2h(out, d_recv)
+        self.dev_free(d_send); self.dev_free(d_recv)
+        return out.reshape((-1,) + a.shape[1:])
 
     def adam_step(self, grad_scale=1.0):
         self._chk(N.lib().dm_adam_step(self._h, float(grad_scale)))
@@ -384,7 +450,7 @@ class Engine:
     def synchronize(self):
         self._chk(N.lib().dm_synchronize(self._h))
 
-    _SCORER = {"f32": 0, "split_f16": 1, "auto": 2}
+    _SCORER = {"f32": 0, "split_f16": 1, "auto": 2, "f64": 3}
 
     def set_scorer_mode(self, mode):
         """Arithmetic of the beam-search scorer: "f32" (fp32-input MFMA), "split_f16" (fp16 hi/lo operand split on the

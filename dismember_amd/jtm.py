@@ -15,7 +15,7 @@ from .engine import Engine, _i32, _p
 
 class JTM:
     def __init__(self, engine: Engine, leaf_item_ids, leaf_codes, max_level, item_rows, gap=2, seq_len=10,
-                 hierarchical=False, min_level=0, use_mask=True, dist=None):
+                 hierarchical=False, min_level=0, use_mask=True, comm=None):
         """item_rows: dict item id -> int array [n_rows * seq_len] (itemSequenceMap, TreeLearning.scala:34-46)."""
         self.engine = engine
         self.items = np.sort(_i32(leaf_item_ids))
@@ -23,7 +23,7 @@ class JTM:
         self.item_code = np.array([lut[int(i)] for i in self.items], np.int32)      # code in the CURRENT tree
         self.max_level, self.gap, self.L = int(max_level), int(gap), int(seq_len)
         self.hierarchical, self.min_level, self.use_mask = bool(hierarchical), int(min_level), bool(use_mask)
-        self.dist = dist              # torch.distributed: items sharded over ranks, weights all-gathered (sharding.py)
+        self.comm = comm              # comm.Comm: items sharded over ranks, weight blocks all-gathered (sharding.py)
         off = np.zeros(self.items.size + 1, np.int64)
         rows = []
         for k, it in enumerate(self.items.tolist()):
@@ -52,9 +52,9 @@ class JTM:
         return w[:n]
 
     def child_weights(self, item_node, old_level, level):
-        """All items; with `dist` every rank scores its contiguous item range and the blocks are all-gathered."""
+        """All items; with `comm` every rank scores its contiguous item range and the blocks are all-gathered."""
         from .sharding import sharded_rows
-        return sharded_rows(lambda lo, hi: self.weights_range(item_node, old_level, level, lo, hi), self.items.size, self.dist)
+        return sharded_rows(lambda lo, hi: self.weights_range(item_node, old_level, level, lo, hi), self.items.size, self.comm)
 
     def rebalance(self, weights, old_node, node, old_level, level, max_assign):
         weights = np.ascontiguousarray(weights, np.float32)

@@ -14,14 +14,14 @@ from .sharding import sharded_rows
 
 
 class TreeConstruction:
-    def __init__(self, engine: Engine, item_id_mapping, item_sequences, gap=2, seq_len=10, use_mask=True, dist=None):
+    def __init__(self, engine: Engine, item_id_mapping, item_sequences, gap=2, seq_len=10, use_mask=True, comm=None):
         """item_id_mapping: item -> leaf node id; item_sequences: item -> flat [rows * seq_len] NODE ids
         (itemSequenceMap, TreeConstruction.scala:36-43: histories already mapped through itemIdMapping)."""
         self.engine = engine
         self.items = np.array(sorted(int(i) for i in item_id_mapping), np.int32)
         self.item_leaf = np.array([item_id_mapping[int(i)] for i in self.items], np.int32)
         self.leaf_level = int(np.ceil(np.log(len(self.items)) / np.log(2)))          # upperLog2, otm/package.scala:16
-        self.gap, self.L, self.use_mask, self.dist = int(gap), int(seq_len), bool(use_mask), dist
+        self.gap, self.L, self.use_mask, self.comm = int(gap), int(seq_len), bool(use_mask), comm
         off = np.zeros(self.items.size + 1, np.int64)
         rows = []
         for k, it in enumerate(self.items.tolist()):
@@ -47,7 +47,7 @@ class TreeConstruction:
         return w[:n]
 
     def child_weights(self, item_node, old_level, level):
-        return sharded_rows(lambda lo, hi: self.weights_range(item_node, old_level, level, lo, hi), self.items.size, self.dist)
+        return sharded_rows(lambda lo, hi: self.weights_range(item_node, old_level, level, lo, hi), self.items.size, self.comm)
 
     def rebalance(self, weights, old_node, node, old_level, level, max_assign):
         weights = np.ascontiguousarray(weights, np.float64)

@@ -19,7 +19,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <fstream>
 #include <map>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -30,6 +32,47 @@
 #include "dismember_hip.h"
 
 namespace dm {
+
+// Property.readConf / getOrStop / getCoreNumber (scalann/src/main/scala/com/mass/scalann/utils/Property.scala:12-71): the
+// reference's `.conf` format, verbatim — lines `prefix.key<whitespace>value`, kept when they START with the prefix and split
+// into exactly two tokens; later duplicates win — so configs/*.conf of the reference load unchanged.
+struct Property {
+  static std::map<std::string, std::string> readConf(const std::string &path, const std::string &prefix, bool truncate = true) {
+    std::ifstream f(path);
+    if (!f) throw std::invalid_argument("requirement failed: Config file " + path + " doesn't exist");
+    std::map<std::string, std::string> out;
+    std::string line;
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\x0b' || c == '\f' || c == '\r'; };
+    while (std::getline(f, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (line.compare(0, prefix.size(), prefix) != 0) continue;
+      size_t a = 0, b = line.size();
+      while (a < b && (unsigned char)line[a] <= ' ') a++;            // String.trim
+      while (b > a && (unsigned char)line[b - 1] <= ' ') b--;
+      std::vector<std::string> tok;
+      for (size_t i = a; i < b;) {
+        size_t j = i;
+        while (j < b && !ws(line[j])) j++;
+        tok.push_back(line.substr(i, j - i));
+        while (j < b && ws(line[j])) j++;
+        i = j;
+      }
+      if (tok.size() != 2) continue;
+      out[truncate ? (tok[0].size() > prefix.size() ? tok[0].substr(prefix.size() + 1) : std::string()) : tok[0]] = tok[1];
+    }
+    return out;
+  }
+  static const std::string &getOrStop(const std::map<std::string, std::string> &conf, const std::string &key) {
+    auto it = conf.find(key);
+    if (it == conf.end()) throw std::invalid_argument("failed to read parameter: " + key + " in conf file");
+    return it->second;
+  }
+  static int getCoreNumber(int confNum) {           // thread_number <= 0: every available processor
+    if (confNum > 0) return confNum;
+    const unsigned n = std::thread::hardware_concurrency();
+    return n ? (int)n : 1;
+  }
+};
 
 struct Error : std::runtime_error {
   int code;

@@ -89,11 +89,16 @@ int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, cons
  *                        separates any two fp32 implementations over E terms (measured: DESIGN.md).  E must be 32, 64 or
  *                        128.  Same stated tolerance as the F32 mode (rtol 1e-4 / atol 1e-5 against the oracle); ids are
  *                        the exact beam search on the scores produced.
- *   DM_SCORER_AUTO       (default) SPLIT_F16 where the embedding size allows it, F32 otherwise (E = 16).
+ *   DM_SCORER_AUTO       (default) SPLIT_F16 where the embedding size allows it, F32 otherwise (E = 16); and for the OTM
+ *                        searches (dm_otm_beam_search*) of a model loaded as DM_F64: DM_SCORER_F64.
+ *   DM_SCORER_F64        OTM searches in the reference's own arithmetic (otm/.../model/DIN.scala:12-39 is DIN[Double]):
+ *                        every product on the fp64 matrix cores, node ids bit-exact against the fp64 oracle given the
+ *                        same scores, scores within 1e-10 / 1e-9.  Needs f64 weights.  This is the parity mode; F32 /
+ *                        SPLIT_F16 (on the f32 copy of the table) remain the throughput modes and can be forced.
  * The brute-force recall oracle (dm_tdm_bruteforce_topk) and every other entry point always use fp32 / fp64 arithmetic.
  * dm_get_scorer_mode: the setting, the arithmetic in effect for the loaded model, and the power-of-two shifts in use
  * (after the first search). */
-enum { DM_SCORER_F32 = 0, DM_SCORER_SPLIT_F16 = 1, DM_SCORER_AUTO = 2 };
+enum { DM_SCORER_F32 = 0, DM_SCORER_SPLIT_F16 = 1, DM_SCORER_AUTO = 2, DM_SCORER_F64 = 3 };
 int dm_set_scorer_mode(dm_handle_t h, int mode);
 int dm_get_scorer_mode(dm_handle_t h, int *mode, int *effective, int *shift_emb, int *shift_w);
 
@@ -138,6 +143,14 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
  * candidates in order (f32 scorer; the reference runs this path in f64 — tolerance in DESIGN.md). */
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts);
+
+/* The same two searches with double outputs, always in fp64 arithmetic (f64 weights required): the scores the reference's
+ * DIN[Double] produces, for the 1e-10 / 1e-9 parity contract. */
+int dm_otm_beam_search_f64(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                           int32_t *out_node_ids, double *out_scores, int32_t *out_counts);
+int dm_otm_beam_search_trace_f64(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
+                                 int32_t *out_node_ids, double *out_scores, int32_t *out_counts, int max_levels,
+                                 int32_t *trace_codes, double *trace_scores, int32_t *trace_counts);
 
 /* Same, dumping every level's scored candidates = OTMTree.beamSearchNodes (O/tree/OTMTree.scala:67-91), which OTM
  * training consumes: trace_* [U * max_levels * cap] / [U * max_levels], cap = 2*beam rounded up to 16 (min 32). */
@@ -208,6 +221,42 @@ int dm_train_dense_block(dm_handle_t h, float **d_ptr, int64_t *n);
 int dm_train_export_rows(dm_handle_t h, int32_t *d_rows, float *d_grads, int64_t cap, int64_t *n);   /* NULL buffers: size query */
 int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const float *d_grads, int64_t n);
 
+/* ---- multi-GPU: communicators and the gradient exchange ------------------------------------------
+ * The reference's data parallelism is N worker threads in one JVM whose gradient buffers are averaged in place
+ * (LocalOptimizer.syncGradients, T/optim/LocalOptimizer.scala:164-187; O/optim/LocalOptimizer.scala:217-233).  Here a worker
+ * is a handle on its own GPU; a dm_comm_t connects the workers:
+ *   DM_COMM_RCCL  RCCL over xGMI, one rank per GPU.  Either one process per GPU (dm_comm_create_rccl with an id from
+ *                 dm_comm_unique_id that the host distributes itself, or dm_comm_create_tcp which distributes it), or ONE
+ *                 process driving every GPU like the reference's JVM (dm_comm_create_all + dm_allreduce_grads).
+ *   DM_COMM_HOST  a TCP star through rank 0, device buffers staged through host memory: several workers sharing one GPU
+ *                 (RCCL refuses two ranks per device) and CPU-only processes for the host-buffer collectives.
+ * dm_train_sync_gradients(h) == syncGradients minus the division (dm_adam_step(1/N) folds it in): all-reduce(sum) of the
+ * dense block + all-gather of (touched row, gradient row) lists, each touched row rebuilt as 0 + g_0 + g_1 + ... in rank
+ * order, so every replica ends with bit-identical gradients.  Collective: every rank must call it. */
+typedef struct dm_comm *dm_comm_t;
+enum { DM_COMM_HOST = 0, DM_COMM_RCCL = 1 };
+#define DM_COMM_ID_BYTES 128
+int dm_comm_unique_id(void *id128);                                  /* ncclGetUniqueId, padded to DM_COMM_ID_BYTES */
+int dm_comm_create_rccl(int nranks, int rank, const void *id128, int device_id, dm_comm_t *out);
+/* rendezvous at addr:port (rank 0 listens); transport DM_COMM_RCCL: the sockets only carry the id.  device_id is ignored
+ * by DM_COMM_HOST (no GPU needed for the host-buffer collectives). */
+int dm_comm_create_tcp(int nranks, int rank, const char *addr, int port, int transport, int device_id, dm_comm_t *out);
+int dm_comm_create_all(int n, const int *devices, dm_comm_t *out /* [n] */);   /* ncclCommInitAll: one process, n GPUs */
+int dm_comm_destroy(dm_comm_t c);
+const char *dm_comm_last_error(dm_comm_t c);                          /* c may be NULL: last create-time error */
+int dm_comm_rank(dm_comm_t c, int *rank, int *nranks, int *transport);
+int dm_comm_barrier(dm_comm_t c);
+int dm_comm_allreduce_f64(dm_comm_t c, double *vals, int n, int op /* 0 sum (rank order), 1 max */);   /* host values, in place */
+/* var-size all-gather of host buffers: recv gets the blocks in rank order, sizes[nranks] their byte lengths; recv == NULL
+ * only fills sizes */
+int dm_comm_all_gather_v(dm_comm_t c, const void *send, size_t bytes, void *recv, size_t recv_cap, uint64_t *sizes);
+int dm_comm_attach(dm_handle_t h, dm_comm_t c);                       /* the handle does not own c; NULL detaches */
+int dm_comm_all_gather_dev(dm_handle_t h, const void *d_send, size_t bytes, void *d_recv, size_t recv_cap, uint64_t *sizes);
+int dm_train_sync_gradients(dm_handle_t h);
+/* SURVEY.md §8b `dm_allreduce_grads(h[], n_gpu)`: the same exchange for ALL ranks of a dm_comm_create_all clique from one
+ * thread (hs[i] must carry rank i); n == 1 is dm_train_sync_gradients. */
+int dm_allreduce_grads(dm_handle_t *hs, int n);
+
 /* Level-wise negative sampling + batch expansion (uniform mode): NegativeSampler.sample
  * (tdm/.../utils/NegativeSampler.scala:76-114,146-158) + MiniBatch.convert (tdm/.../dataset/MiniBatch.scala:49-88).
  * seq_item_ids [T*L], target_item_ids [T]; neg_counts = model.layer_negative_counts (>= max_level+1 entries).
@@ -217,6 +266,9 @@ int dm_tdm_make_train_batch(dm_handle_t h, const int32_t *seq_item_ids, const in
                             const int32_t *neg_counts, int n_counts, int start_level, uint64_t seed, int use_mask,
                             int32_t *out_codes, int32_t *out_seqs, uint32_t *out_rowmask, float *out_labels, int64_t cap,
                             int64_t *n_rows);
+/* dm_train_forward_backward on rows that already live in device memory (the output of dm_tdm_sample_train_batch_dev or of
+ * a caller's own sampler).  Asynchronous unless `loss` is non-NULL.  The ids are NOT range-checked (the host-buffer entry
+ * point validates them like LookupTable.scala:29-53): every code / history entry must be -1 or in [0, num_index). */
 int dm_train_forward_backward_dev(dm_handle_t h, const int32_t *d_codes, const int32_t *d_seqs, const uint32_t *d_rowmask,
                                   const float *d_labels, int64_t B, int L, float *loss);
 int dm_memcpy_d2d(dm_handle_t h, void *dst, const void *src, size_t bytes);

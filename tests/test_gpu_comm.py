@@ -1,0 +1,109 @@
+"""The gradient exchange behind the C ABI (dm_train_sync_gradients = LocalOptimizer.syncGradients,
+tdm/src/main/scala/com/mass/tdm/optim/LocalOptimizer.scala:164-187) on real engines.
+
+A GPU box has ONE device and RCCL refuses two ranks per device, so the multi-worker protocol runs as W processes sharing
+the GPU over the library's host transport (same entry point, same kernels: export, zero, rank-ordered re-summation; only
+the wire differs), and RCCL itself is exercised as a single-rank communicator (ncclCommInitRank, ncclBroadcast path of
+dm_comm_all_gather_dev)."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batch(rank, B=96, L=10, NI=8191):
+    rng = np.random.default_rng(500 + rank)
+    codes = rng.integers(1, NI, B).astype(np.int32)
+    seqs = rng.integers(0, 400, (B, L)).astype(np.int32)        # a small history vocabulary: most rows are touched by every worker
+    seqs[rng.random((B, L)) < 0.2] = -1
+    labels = (rng.random(B) < 0.3).astype(np.float32)
+    return codes, seqs, np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32), labels
+
+
+def _worker(rank, world, port, q, scale):
+    from dismember_amd import Engine
+    from dismember_amd.comm import Comm
+    w = np.load(os.path.join(GOLDEN, "din_f32.npy"))
+    eng = Engine(0)
+    eng.load_weights_din(w, 16, 8191)
+    eng.train_init(lr=1e-3)
+    comm = Comm(world, rank, "127.0.0.1", port, transport="host")
+    eng.attach_comm(comm)
+    codes, seqs, pad, y = _batch(rank)
+    y = y * np.float32(scale ** rank)           # very different gradient magnitudes per worker: the summation order is visible
+    loss = eng.train_forward_backward(codes, seqs, pad, y)
+    local = eng.train_download("grad")
+    eng.train_sync_gradients()
+    summed = eng.train_download("grad")
+    eng.adam_step(1.0 / world)
+    wts = eng.train_download("weights")
+    gathered = eng.comm_all_gather_dev(np.full((rank + 2, 3), rank, np.int32))
+    q.put((rank, loss, local, summed, wts, gathered))
+    comm.barrier()
+    eng.close(); comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sync_gradients_replicas_bit_identical(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 37.0)) for r in range(world)]
+    [p.start() for p in procs]
+    out = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want = np.zeros_like(out[0][2])
+    for r in range(world):
+        want = want + out[r][2]                 # float32, rank order: 0 + g_0 + g_1 + ... exactly what every replica forms
+    touched = np.flatnonzero(np.abs(want[:8191 * 16]).reshape(8191, 16).sum(1) > 0)
+    assert touched.size > 300
+    for r in range(world):
+        assert np.array_equal(out[r][3], want), r                       # the sum, bit for bit, on every replica
+        assert np.array_equal(out[r][4], out[0][4])                      # and identical weights after the Adam step
+        assert np.array_equal(out[r][5], np.concatenate([np.full((k + 2, 3), k, np.int32) for k in range(world)]))
+    assert not np.array_equal(out[0][4], np.load(os.path.join(GOLDEN, "din_f32.npy")))
+
+
+def test_rccl_single_rank_communicator():
+    from dismember_amd import Engine
+    from dismember_amd.comm import Comm
+    eng = Engine(0)
+    eng.load_weights_din(np.load(os.path.join(GOLDEN, "din_f32.npy")), 16, 8191)
+    eng.train_init(lr=1e-3)
+    comm = Comm(1, 0, "127.0.0.1", _free_port(), transport="rccl", device_id=0)       # ncclCommInitRank on the real device
+    eng.attach_comm(comm)
+    codes, seqs, pad, y = _batch(0)
+    eng.train_forward_backward(codes, seqs, pad, y)
+    g0 = eng.train_download("grad")
+    eng.train_sync_gradients()                                                        # one worker: the gradient is its own
+    assert np.array_equal(eng.train_download("grad"), g0)
+    a = np.arange(24, dtype=np.float32).reshape(8, 3)
+    assert np.array_equal(eng.comm_all_gather_dev(a), a)                              # ncclBroadcast through RCCL
+    assert comm.allreduce([1.5, 2.0]).tolist() == [1.5, 2.0] and comm.all_gather_bytes(b"abc") == [b"abc"]
+    comm.barrier()
+    eng.close(); comm.close()
+
+
+def test_sync_without_communicator_fails():
+    from dismember_amd import DismemberError, Engine
+    eng = Engine(0)
+    eng.load_weights_din(np.load(os.path.join(GOLDEN, "din_f32.npy")), 16, 8191)
+    eng.train_init()
+    with pytest.raises(DismemberError) as e:
+        eng.train_sync_gradients()
+    assert e.value.code == -3
+    eng.close()

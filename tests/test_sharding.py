@@ -1,5 +1,9 @@
-"""N>1 path on CPU: two gloo processes shard users, agree on the slowest-rank clock and
-reassemble results in user order (what bench.py --gpus N does with RCCL on GPUs)."""
+"""N>1 path on CPU.  Two kinds of worker processes:
+  * the library's own HOST transport (dm_comm_create_tcp, no GPU needed for the host-buffer collectives): what
+    bench.py --gpus N and the trainers use, with RCCL as the transport on GPUs;
+  * a gloo adapter with the same interface (world_size 2), which pins the sharding helpers against torch.distributed.
+The device half of the exchange (dm_train_sync_gradients) is covered on the GPU by tests/test_gpu_comm.py."""
+import multiprocessing as mp
 import os
 import socket
 
@@ -7,6 +11,26 @@ import numpy as np
 import pytest
 
 from dismember_amd.sharding import shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(target, world, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    [p.start() for p in procs]
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    return out
 
 
 def test_shard_range_partitions_contiguously():
@@ -19,138 +43,95 @@ def test_shard_range_partitions_contiguously():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
-    from dismember_amd import sharding
-    dist, r, w, _ = sharding.init_distributed("gloo")
-    n_users = 101
-    lo, hi = sharding.shard_range(n_users, r, w)
-    # stand-in for the per-rank beam search: "ids" derived from the global user index
-    local = np.stack([np.arange(lo, hi) * 10 + k for k in range(3)], axis=1).astype(np.int32)
-    dist.barrier()
-    slowest = sharding.max_over_ranks(1.0 + r, dist)
-    allids = sharding.gather_results(local, dist)
-    q.put((r, slowest, allids.shape, bool((allids[:, 0] == np.arange(n_users) * 10).all())))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_two_rank_gloo_sharding():
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
-    out = sorted(q.get(timeout=120) for _ in range(2))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    for r, slowest, shape, ordered in out:
-        assert slowest == 2.0 and shape == (101, 3) and ordered
-
-
-# ---- gradient exchange protocol of the data-parallel trainer (3 gloo ranks, torch-backed fake engines) ----
-class _FakePort:
-    """Stands in for EngineGradPort: a dense block and a row-sparse embedding gradient held in torch CPU tensors."""
-
-    def __init__(self, torch, rank, n_rows=50, E=4):
-        g = torch.Generator().manual_seed(100 + rank)
-        self.torch = torch
-        self.dense_block = torch.randn(37, generator=g)
-        self.table = torch.zeros(n_rows, E)
-        idx = torch.randperm(n_rows, generator=g)[:30]          # 30 of 50 rows: most rows are touched by several workers
-        self.table[idx] = torch.randn(30, E, generator=g) * (10.0 ** float(rank))     # magnitudes that make the order matter
-        self.touched = idx.to(torch.int32)
-
-    def dense(self):
-        return self.dense_block.clone()
-
-    def set_dense(self, t):
-        self.dense_block = t.clone()
-
-    def export_rows(self):
-        return self.touched, self.table[self.touched.long()].clone()
-
-    def add_rows(self, rows, grads):
-        self.table.index_add_(0, rows.long(), grads)
-
-
-def _exchange_worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
-    import torch
-    from dismember_amd import sharding
-    from dismember_amd.trainer import exchange_gradients
-    dist, r, w, _ = sharding.init_distributed("gloo")
-    ports = [_FakePort(torch, k) for k in range(world)]        # every rank can rebuild every rank's local gradient
-    mine = ports[r]
-    n = exchange_gradients(mine, dist, torch)
-    want_dense = sum(p.dense_block for p in [_FakePort(torch, k) for k in range(world)])
-    want_table = sum(p.table for p in [_FakePort(torch, k) for k in range(world)])
-    q.put((r, n, bool(torch.allclose(mine.dense_block, want_dense)), bool(torch.allclose(mine.table, want_table, rtol=1e-5, atol=1e-5)),
-           mine.table.numpy().tobytes()))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_three_rank_gradient_exchange_bit_identical_replicas():
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, q)) for r in range(3)]
-    [p.start() for p in procs]
-    out = sorted(q.get(timeout=120) for _ in range(3))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    assert all(n == 3 and dense_ok and table_ok for _, n, dense_ok, table_ok, _ in out)
-    assert out[0][4] == out[1][4] == out[2][4]          # every replica holds the same bits (rows summed in rank order)
-
-
-# ---- item-sharded JTM child weights (2 gloo ranks; the per-item row function stands in for the GPU scorer) ----
+# ---- item-sharded JTM child weights (the per-item row function stands in for the GPU scorer) ----
 def _jtm_rows(lo, hi):
     i = np.arange(lo, hi, dtype=np.float64)[:, None]
     return (np.sin(i * 0.37 + np.arange(4)[None, :]) * 1000).astype(np.float32)
 
 
-def _jtm_worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+def _serve_and_jtm(comm, q):
     from dismember_amd import sharding
-    dist, r, w, _ = sharding.init_distributed("gloo")
+    r, w = comm.rank, comm.world
+    n_users = 101
+    lo, hi = sharding.shard_range(n_users, r, w)
+    # stand-in for the per-rank beam search: "ids" derived from the global user index
+    local = np.stack([np.arange(lo, hi) * 10 + k for k in range(3)], axis=1).astype(np.int32)
+    comm.barrier()
+    slowest = sharding.max_over_ranks(1.0 + r, comm)
+    allids = sharding.gather_results(local, comm)
     calls = []
 
-    def compute(lo, hi):
-        calls.append((lo, hi))
-        return _jtm_rows(lo, hi)
+    def compute(a, b):
+        calls.append((a, b))
+        return _jtm_rows(a, b)
 
-    full = sharding.sharded_rows(compute, 37, dist)
-    q.put((r, calls, bool(np.array_equal(full, _jtm_rows(0, 37)))))
-    dist.barrier()
+    full = sharding.sharded_rows(compute, 37, comm)
+    total = comm.allreduce([float(r + 1), 0.5])
+    q.put((r, slowest, allids.shape, bool((allids[:, 0] == np.arange(n_users) * 10).all()), calls,
+           bool(np.array_equal(full, _jtm_rows(0, 37))), total.tolist()))
+    comm.barrier()
+
+
+def _host_worker(rank, world, port, q):
+    from dismember_amd.comm import Comm
+    comm = Comm(world, rank, "127.0.0.1", port, transport="host")
+    _serve_and_jtm(comm, q)
+    # ragged payloads (rank r sends r * 1000 + 3 bytes; rank 0's may be empty elsewhere in the protocol)
+    blocks = comm.all_gather_bytes(bytes([rank + 1]) * (rank * 1000 + 3))
+    assert [len(b) for b in blocks] == [r * 1000 + 3 for r in range(world)] and all(set(b) == {r + 1} for r, b in enumerate(blocks))
+    assert comm.all_gather_bytes(b"") == [b""] * world
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_transport_sharding(world):
+    out = _run(_host_worker, world)
+    for r, slowest, shape, ordered, calls, same, total in out:
+        assert slowest == float(world) and shape == (101, 3) and ordered
+        assert calls == [shard_range(37, r, world)] and same      # each rank scored only its own items; bit-identical full matrix
+        assert total == [world * (world + 1) / 2, 0.5 * world]
+
+
+class GlooComm:
+    """torch.distributed (gloo) behind the comm interface the sharding helpers use — test infrastructure only."""
+
+    def __init__(self, dist):
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def allreduce(self, values, op="sum"):
+        import torch
+        t = torch.tensor(np.atleast_1d(np.asarray(values, np.float64)))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+        return t.numpy() if np.ndim(values) else float(t[0])
+
+    def all_gather_array(self, arr):
+        objs = [None] * self.world
+        self.dist.all_gather_object(objs, np.ascontiguousarray(arr))
+        return np.concatenate(objs, axis=0)
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    _serve_and_jtm(GlooComm(dist), q)
     dist.destroy_process_group()
 
 
-def test_two_rank_item_sharded_rows():
-    import torch.multiprocessing as mp
-    from dismember_amd import sharding
-    assert np.array_equal(sharding.sharded_rows(_jtm_rows, 5, None), _jtm_rows(0, 5))     # single rank: whole range
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_jtm_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
-    out = sorted(q.get(timeout=120) for _ in range(2))
-    [p.join(60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    assert out[0][1] == [(0, 19)] and out[1][1] == [(19, 37)]        # each rank scored only its own items
-    assert out[0][2] and out[1][2]                                     # and both hold the bit-identical full matrix
+def test_two_rank_gloo_sharding():
+    out = _run(_gloo_worker, 2)
+    for r, slowest, shape, ordered, calls, same, total in out:
+        assert slowest == 2.0 and shape == (101, 3) and ordered and same and calls == [shard_range(37, r, 2)]
+
+
+def test_comm_create_errors():
+    from dismember_amd.comm import Comm, CommError
+    with pytest.raises(CommError):
+        Comm(2, 5, "127.0.0.1", 1234, transport="host")          # rank outside [0, nranks)
+    c = Comm(1, 0, "127.0.0.1", _free_port(), transport="host")   # a single rank needs no peer
+    assert c.allreduce(3.0, "max") == 3.0 and c.all_gather_bytes(b"xy") == [b"xy"]
+    c.close()
