@@ -32,6 +32,10 @@ class DrModel(C.Structure):
                 ("softmax_w", C.c_void_p), ("softmax_b", C.c_void_p)]
 
 
+class SampleOpts(C.Structure):
+    _fields_ = [("start_level", C.c_int), ("with_prob", C.c_int), ("tolerance", C.c_int), ("use_mask", C.c_int), ("seed", C.c_uint64)]
+
+
 class SearchOpts(C.Structure):
     _fields_ = [("beam", C.c_int), ("topk", C.c_int), ("use_mask", C.c_int), ("widen_consumed", C.c_int)]
 
@@ -73,8 +77,11 @@ SIGNATURES = {
     "dm_train_dense_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "dm_train_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
     "dm_train_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
-    "dm_tdm_make_train_batch": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64, C.c_int, i32p, C.c_int, C.c_int, C.c_uint64, C.c_int,
+    "dm_tdm_set_node_probs": (C.c_int, [C.c_void_p, i32p, f32p, C.c_int64]),
+    "dm_tdm_make_train_batch": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64, C.c_int, i32p, C.c_int, C.POINTER(SampleOpts),
                                           i32p, i32p, C.POINTER(C.c_uint32), f32p, C.c_int64, i64p]),
+    "dm_tdm_sample_train_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, i32p, C.c_int,
+                                                C.POINTER(SampleOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
     "dm_train_forward_backward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                 f32p]),
     "dm_dr_load_model": (C.c_int, [C.c_void_p, C.POINTER(DrModel)]),

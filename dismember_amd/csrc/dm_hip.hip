@@ -87,6 +87,12 @@ struct dm_ctx {
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
+  // device-side negative sampler (sampler.hip.inc): per-level code / cumulative-probability tables, per-call scratch
+  int32_t *d_lv_codes = nullptr;
+  double *d_lv_cdf = nullptr;
+  int64_t *d_lv_start = nullptr;
+  void *d_samp = nullptr;
+  size_t samp_bytes = 0;
   // multi-GPU exchange (comm.hip.inc): the attached communicator (not owned) and the staging area of dm_train_sync_gradients
   struct dm_comm *comm = nullptr;
   void *d_sync = nullptr;
@@ -270,6 +276,8 @@ int dm_create(int device_id, dm_handle_t *out) {
 }
 
 static void free_tree(dm_ctx *h) {
+  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start);
+  h->d_lv_codes = nullptr; h->d_lv_cdf = nullptr; h->d_lv_start = nullptr;
   dm_free_ptr(h->d_exists); dm_free_ptr(h->d_leaf); dm_free_ptr(h->d_node_id); dm_free_ptr(h->d_leaf_codes);
   h->d_exists = h->d_leaf = nullptr; h->d_node_id = h->d_leaf_codes = nullptr; h->tree_loaded = false;
 }
@@ -292,6 +300,7 @@ int dm_destroy(dm_handle_t h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
+  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1229,6 +1238,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 
 #include "jtm_host.hip.inc"
 #include "train_host.hip.inc"
+#include "sampler.hip.inc"
 #include "dr_host.hip.inc"
 #include "otm64.hip.inc"
 #include "comm.hip.inc"

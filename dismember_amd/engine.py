@@ -256,25 +256,66 @@ class Engine:
                                                     _p(lab, N.f32p), B, L, C.byref(loss)))
         return loss.value
 
-    def make_train_batch(self, seq_item_ids, target_item_ids, neg_counts, start_level=1, seed=0, use_mask=True):
-        """NegativeSampler.sample + MiniBatch.convert: (codes [R], seqs [R, L], rowmask [R], labels [R])."""
+    def set_node_probs(self, codes, probs):
+        """Node.probality per tree node (needed by sample_with_probability)."""
+        c = _i32(codes); pr = np.ascontiguousarray(probs, np.float32)
+        self._chk(N.lib().dm_tdm_set_node_probs(self._h, _p(c, N.i32p), _p(pr, N.f32p), c.size))
+
+    def make_train_batch(self, seq_item_ids, target_item_ids, neg_counts, start_level=1, seed=0, use_mask=True, with_prob=False,
+                         tolerance=20):
+        """NegativeSampler.sample + MiniBatch.convert (sampled on the device): (codes [R], seqs [R, L], rowmask [R], labels [R])."""
         seq = _i32(seq_item_ids)
         tgt = _i32(target_item_ids).ravel()
         T, L = seq.shape
         neg = _i32(neg_counts)
+        o = N.SampleOpts(int(start_level), int(bool(with_prob)), int(tolerance), int(bool(use_mask)), int(seed))
         n = C.c_int64(0)
         self._chk(N.lib().dm_tdm_make_train_batch(self._h, _p(seq, N.i32p), _p(tgt, N.i32p), T, L, _p(neg, N.i32p), neg.size,
-                                                  int(start_level), int(seed), int(bool(use_mask)), None, None, None, None, 0,
-                                                  C.byref(n)))
+                                                  C.byref(o), None, None, None, None, 0, C.byref(n)))
         R = n.value
         codes = np.empty(max(R, 1), np.int32); seqs = np.empty((max(R, 1), L), np.int32)
         mask = np.empty(max(R, 1), np.uint32); lab = np.empty(max(R, 1), np.float32)
         self._chk(N.lib().dm_tdm_make_train_batch(self._h, _p(seq, N.i32p), _p(tgt, N.i32p), T, L, _p(neg, N.i32p), neg.size,
-                                                  int(start_level), int(seed), int(bool(use_mask)), _p(codes, N.i32p),
-                                                  _p(seqs, N.i32p), mask.ctypes.data_as(C.POINTER(C.c_uint32)), _p(lab, N.f32p),
-                                                  R, C.byref(n)))
+                                                  C.byref(o), _p(codes, N.i32p), _p(seqs, N.i32p),
+                                                  mask.ctypes.data_as(C.POINTER(C.c_uint32)), _p(lab, N.f32p), R, C.byref(n)))
         R = n.value
         return codes[:R], seqs[:R], mask[:R], lab[:R]
+
+    def train_step_sampled(self, seq_item_ids, target_item_ids, neg_counts, start_level=1, seed=0, use_mask=True, with_prob=False,
+                           tolerance=20):
+        """convertBatch + trainBatch with the rows resident in HBM: targets and histories are uploaded (40 B per target),
+        dm_tdm_sample_train_batch_dev expands them on the device straight into the buffers of
+        dm_train_forward_backward_dev.  Returns the mean BCE loss of the expanded rows."""
+        seq = _i32(seq_item_ids)
+        tgt = _i32(target_item_ids).ravel()
+        T, L = seq.shape
+        neg = _i32(neg_counts)
+        o = N.SampleOpts(int(start_level), int(bool(with_prob)), int(tolerance), int(bool(use_mask)), int(seed))
+        n = C.c_int64(0)
+        self._chk(N.lib().dm_tdm_sample_train_batch_dev(self._h, None, None, T, L, _p(neg, N.i32p), neg.size, C.byref(o), None, None,
+                                                        None, None, 0, C.byref(n)))
+        R = max(n.value, 1)
+        need = T * L * 4 + T * 4 + R * 4 * (3 + L) + 1024
+        if getattr(self, "_samp_bytes", 0) < need:
+            if getattr(self, "_samp_buf", None):
+                self.dev_free(self._samp_buf)
+            self._samp_buf, self._samp_bytes = self.dev_alloc(need + need // 2), need + need // 2
+        al = lambda v: (v + 255) & ~255
+        base = self._samp_buf.value
+        d_seq = C.c_void_p(base); base += al(T * L * 4)
+        d_tgt = C.c_void_p(base); base += al(T * 4)
+        d_codes = C.c_void_p(base); base += al(R * 4)
+        d_seqs = C.c_void_p(base); base += al(R * L * 4)
+        d_mask = C.c_void_p(base); base += al(R * 4)
+        d_lab = C.c_void_p(base)
+        self.h2d(d_seq, seq); self.h2d(d_tgt, tgt)
+        self._chk(N.lib().dm_tdm_sample_train_batch_dev(self._h, d_seq, d_tgt, T, L, _p(neg, N.i32p), neg.size, C.byref(o), d_codes,
+                                                        d_seqs, d_mask, d_lab, R, C.byref(n)))
+        if n.value == 0:
+            return 0.0
+        loss = C.c_float(0)
+        self._chk(N.lib().dm_train_forward_backward_dev(self._h, d_codes, d_seqs, d_mask, d_lab, n.value, L, C.byref(loss)))
+        return loss.value
 
     @staticmethod
     def rowmask_to_flat(mask, L):

@@ -257,15 +257,32 @@ int dm_train_sync_gradients(dm_handle_t h);
  * thread (hs[i] must carry rank i); n == 1 is dm_train_sync_gradients. */
 int dm_allreduce_grads(dm_handle_t *hs, int n);
 
-/* Level-wise negative sampling + batch expansion (uniform mode): NegativeSampler.sample
- * (tdm/.../utils/NegativeSampler.scala:76-114,146-158) + MiniBatch.convert (tdm/.../dataset/MiniBatch.scala:49-88).
+/* Level-wise negative sampling + batch expansion, ON THE DEVICE: NegativeSampler.sample
+ * (tdm/.../utils/NegativeSampler.scala:76-158: uniform and sample_with_probability modes) + MiniBatch.convert
+ * (tdm/.../dataset/MiniBatch.scala:49-88).  One wave per (target, level); counter-based stream splitmix64(seed, target,
+ * level, draw) — the reference's RNG is unseeded, so parity with it is distributional; the CPU oracle reproduces this
+ * stream bit for bit.
  * seq_item_ids [T*L], target_item_ids [T]; neg_counts = model.layer_negative_counts (>= max_level+1 entries).
- * Rows per target = sum_{l=start_level}^{max_level} (1 + neg_counts[l]); call with out_codes == NULL for the size.
- * out_rowmask bit j = history position j masked.  Seeded (the reference is not): distributional parity only. */
+ * Rows per target = sum_{l=start_level}^{level of the target} (1 + neg_counts[l]) (targets outside the tree: none);
+ * out_codes == NULL returns the upper bound T * sum_{l=start_level}^{max_level} (1 + neg_counts[l]) in *n_rows.
+ * out_rowmask bit j = history position j masked; seq_len <= 32. */
+typedef struct {
+  int start_level;     /* model.start_sample_level (>= 1) */
+  int with_prob;       /* model.sample_with_probability: draw from the level's node probabilities (dm_tdm_set_node_probs) */
+  int tolerance;       /* model.sample_tolerance: categorical draws per level = neg + tolerance, then a uniform fill */
+  int use_mask;        /* 1 for DIN */
+  uint64_t seed;
+} dm_sample_opts;
+/* Node.probality of the tree nodes (T/tree/DistTree.scala:60-75; levelProbs, NegativeSampler.scala:59-66) */
+int dm_tdm_set_node_probs(dm_handle_t h, const int32_t *codes, const float *probs, int64_t n);
+/* host buffers in and out (the sampling itself runs on the device) */
 int dm_tdm_make_train_batch(dm_handle_t h, const int32_t *seq_item_ids, const int32_t *target_item_ids, int64_t T, int L,
-                            const int32_t *neg_counts, int n_counts, int start_level, uint64_t seed, int use_mask,
-                            int32_t *out_codes, int32_t *out_seqs, uint32_t *out_rowmask, float *out_labels, int64_t cap,
-                            int64_t *n_rows);
+                            const int32_t *neg_counts, int n_counts, const dm_sample_opts *opts, int32_t *out_codes,
+                            int32_t *out_seqs, uint32_t *out_rowmask, float *out_labels, int64_t cap, int64_t *n_rows);
+/* device buffers in and out: the rows land where dm_train_forward_backward_dev reads them; neg_counts is a host array */
+int dm_tdm_sample_train_batch_dev(dm_handle_t h, const int32_t *d_seq_item_ids, const int32_t *d_target_item_ids, int64_t T, int L,
+                                  const int32_t *neg_counts, int n_counts, const dm_sample_opts *opts, int32_t *d_codes,
+                                  int32_t *d_seqs, uint32_t *d_rowmask, float *d_labels, int64_t cap, int64_t *n_rows);
 /* dm_train_forward_backward on rows that already live in device memory (the output of dm_tdm_sample_train_batch_dev or of
  * a caller's own sampler).  Asynchronous unless `loss` is non-NULL.  The ids are NOT range-checked (the host-buffer entry
  * point validates them like LookupTable.scala:29-53): every code / history entry must be -1 or in [0, num_index). */

@@ -666,5 +666,120 @@ int orc_jtm_rebalance(const int32_t *items, const float *weights, const int32_t 
   return 0;
 }
 
+
+/* ------------------------------------------------------------- level-wise negative sampling (row A10)
+ * NegativeSampler.sample / sampleFromUniformDistribution / sampleFromCategoricalDistribution
+ * (T/utils/NegativeSampler.scala:76-158) + MiniBatch.convert / transformWithMask (T/dataset/MiniBatch.scala:49-88,129-147).
+ * The reference draws from an unseeded ThreadLocalRandom / MersenneTwister(System.nanoTime()), so no draw-for-draw parity
+ * with the JVM exists; this restatement keeps the reference's ALGORITHM (per level: distinct existing codes != the positive,
+ * emitted after the positive in ascending order; categorical mode: at most negNum + tolerance draws from the level's
+ * node-probability distribution, then a uniform fill that — as in the reference, :131-137 — does not exclude the positive)
+ * and plugs in the product's counter-based stream splitmix64(seed, target, level, draw), so that the device sampler can be
+ * compared with it bit for bit.
+ */
+static uint64_t orc_splitmix(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static uint64_t orc_draw(uint64_t seed, int64_t t, int level, uint64_t ctr, int stream) {
+  return orc_splitmix(seed ^ orc_splitmix((uint64_t)t * 64 + (uint64_t)level + ((uint64_t)stream << 40)) ^ (ctr * 0xD6E8FEB86659FD93ull));
+}
+static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return x < y ? -1 : x > y; }
+
+/* node_codes/node_probs [n_prob]: Node.probality of every tree node (only read when with_prob).  Outputs as
+ * dm_tdm_make_train_batch: out_codes/out_labels/out_rowmask [rows], out_seqs [rows*L]; returns the number of rows. */
+int64_t orc_tdm_sample_batch(void *tree, const int32_t *seq_item_ids, const int32_t *target_item_ids, int64_t T, int L,
+                             const int32_t *neg_counts, int start_level, uint64_t seed, int use_mask, int with_prob,
+                             int tolerance, const int32_t *node_codes, const float *node_probs, int64_t n_prob,
+                             int32_t *out_codes, int32_t *out_seqs, uint32_t *out_rowmask, float *out_labels) {
+  orc_tree_t *t = (orc_tree_t *)tree;
+  const int total_level = t->max_level + 1;
+  /* levelProbs (:59-66): existing codes of a level in ascending order with their probabilities; EnumeratedIntegerDistribution
+   * normalises them and samples by inverse CDF */
+  float *prob_of = NULL;
+  if (with_prob) {
+    prob_of = (float *)calloc(t->n_slots > 0 ? t->n_slots : 1, sizeof(float));
+    for (int64_t i = 0; i < n_prob; i++) if (node_codes[i] >= 0 && node_codes[i] < t->n_slots) prob_of[node_codes[i]] = node_probs[i];
+  }
+  int32_t *seq_codes = (int32_t *)malloc(sizeof(int32_t) * L);
+  int32_t *negs = (int32_t *)malloc(sizeof(int32_t) * 4096);
+  int64_t q = 0;
+  for (int64_t ti = 0; ti < T; ti++) {
+    uint32_t m = 0;
+    for (int j = 0; j < L; j++) {     /* TDMTree.idToCode, T/tree/TDMTree.scala:35-56 */
+      int32_t id = seq_item_ids[ti * L + j], cd;
+      if (id == 0) { cd = -1; m |= 1u << j; }
+      else if (id < t->non_leaf_offset && id >= 0 && t->id_to_code[id] >= 0) cd = t->id_to_code[id];
+      else { cd = (int32_t)((uint32_t)id - (uint32_t)t->non_leaf_offset); if (cd > t->max_code) { cd = -1; m |= 1u << j; } }
+      seq_codes[j] = cd;
+    }
+    int32_t tid = target_item_ids[ti], tcode = -1;
+    if (tid > 0 && tid < t->non_leaf_offset && t->id_to_code[tid] >= 0) tcode = t->id_to_code[tid];
+    if (tcode <= 0 || !tree_contains(t, tcode)) continue;      /* pathNodes of an unknown target is empty (:70-77) */
+    int depth = 0;
+    for (int64_t c = tcode; c > 0; c = (c - 1) >> 1) depth++;
+    for (int level = start_level; level < total_level && level <= depth; level++) {
+      int64_t pos = tcode;
+      for (int d = depth; d > level; d--) pos = (pos - 1) >> 1;
+      const int64_t lo = ((int64_t)1 << level) - 1, width = (int64_t)1 << level;
+      const int want = neg_counts[level];
+      int n = 0;
+      if (with_prob) {
+        /* the level's distribution */
+        int64_t ne = 0;
+        for (int64_t c = lo; c < lo + width; c++) if (tree_contains(t, c)) ne++;
+        int32_t *codes = (int32_t *)malloc(sizeof(int32_t) * (ne > 0 ? ne : 1));
+        double *cdf = (double *)malloc(sizeof(double) * (ne > 0 ? ne : 1));
+        double sum = 0.0;
+        int64_t k = 0;
+        for (int64_t c = lo; c < lo + width; c++) if (tree_contains(t, c)) { codes[k] = (int32_t)c; sum += (double)prob_of[c]; k++; }
+        double acc = 0.0;
+        for (k = 0; k < ne; k++) { acc += (double)prob_of[codes[k]] / sum; cdf[k] = acc; }
+        for (uint64_t ctr = 0; n < want && ctr < (uint64_t)(want + tolerance); ctr++) {       /* :120-126 */
+          const double u = (double)(orc_draw(seed, ti, level, ctr, 0) >> 11) * (1.0 / 9007199254740992.0);
+          int64_t a = 0, b = ne;                    /* first index with u < cdf[index]; the last one when there is none */
+          while (a < b) { int64_t mid = (a + b) >> 1; if (u < cdf[mid]) b = mid; else a = mid + 1; }
+          if (a >= ne) a = ne - 1;
+          const int32_t s = codes[a];
+          int dup = 0;
+          for (int i = 0; i < n; i++) dup |= negs[i] == s;
+          if (!dup && s != pos) negs[n++] = s;
+        }
+        free(codes); free(cdf);
+        /* :127-139 — the uniform fill after the tolerance is used up does NOT exclude the positive (reference behaviour) */
+        const uint64_t limit = 64ull * (uint64_t)(want + 1) + 4096ull * (uint64_t)width;
+        for (uint64_t ctr = 0; n < want && ctr <= limit; ctr++) {
+          const int64_t sc = lo + (int64_t)(orc_draw(seed, ti, level, ctr, 1) % (uint64_t)width);
+          if (!tree_contains(t, sc)) continue;
+          int dup = 0;
+          for (int i = 0; i < n; i++) dup |= negs[i] == (int32_t)sc;
+          if (!dup) negs[n++] = (int32_t)sc;
+        }
+      } else {
+        /* :146-158; the product bounds the rejection loop (a level with fewer than want + 1 existing nodes would spin forever) */
+        const uint64_t limit = 64ull * (uint64_t)(want + 1) + 4096ull * (uint64_t)width;
+        for (uint64_t ctr = 0; n < want && ctr <= limit; ctr++) {
+          const int64_t sc = lo + (int64_t)(orc_draw(seed, ti, level, ctr, 0) % (uint64_t)width);
+          if (sc == pos || !tree_contains(t, sc)) continue;
+          int dup = 0;
+          for (int i = 0; i < n; i++) dup |= negs[i] == (int32_t)sc;
+          if (!dup) negs[n++] = (int32_t)sc;
+        }
+      }
+      qsort(negs, n, sizeof(int32_t), cmp_i32);          /* BitSet.toList: ascending */
+      for (int k = 0; k <= n; k++, q++) {
+        out_codes[q] = k == 0 ? (int32_t)pos : negs[k - 1];
+        out_labels[q] = k == 0 ? 1.0f : 0.0f;
+        memcpy(out_seqs + q * L, seq_codes, sizeof(int32_t) * L);
+        out_rowmask[q] = use_mask ? m : 0u;
+      }
+    }
+  }
+  free(seq_codes); free(negs); free(prob_of);
+  return q;
+}
+
 /* ------------------------------------------------------------- Deep-Retrieval (row A13) */
 #include "dr_body.inc"

@@ -272,6 +272,28 @@ class TdmTree:
         return oi[:k].copy()
 
 
+def tdm_sample_batch(tree, seq_item_ids, target_item_ids, neg_counts, start_level=1, seed=0, use_mask=True, with_prob=False,
+                     tolerance=20, node_codes=None, node_probs=None):
+    """NegativeSampler.sample + MiniBatch.convert with the product's counter-based stream: (codes, seqs, rowmask, labels)."""
+    seq = _i32(seq_item_ids)
+    tgt = _i32(target_item_ids).ravel()
+    T, L = seq.shape
+    neg = _i32(neg_counts)
+    per = int(sum(1 + int(neg[l]) for l in range(start_level, tree.max_level + 1)))
+    cap = max(T * per, 1)
+    codes = np.empty(cap, np.int32); seqs = np.empty((cap, L), np.int32); mask = np.empty(cap, np.uint32); lab = np.empty(cap, np.float32)
+    nc = _i32([] if node_codes is None else node_codes)
+    npb = np.ascontiguousarray([] if node_probs is None else node_probs, dtype=np.float32)
+    fn = lib().orc_tdm_sample_batch
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, i32p, i32p, C.c_int64, C.c_int, i32p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int64,
+                   i32p, i32p, C.POINTER(C.c_uint32), f32p]
+    n = fn(tree.h, _p(seq, i32p), _p(tgt, i32p), T, L, _p(neg, i32p), int(start_level), int(seed), int(bool(use_mask)),
+           int(bool(with_prob)), int(tolerance), _p(nc, i32p), _p(npb, f32p), nc.size, _p(codes, i32p), _p(seqs, i32p),
+           mask.ctypes.data_as(C.POINTER(C.c_uint32)), _p(lab, f32p))
+    return codes[:n].copy(), seqs[:n].copy(), mask[:n].copy(), lab[:n].copy()
+
+
 def level_start(n):
     s, l = C.c_int(0), C.c_int(0)
     lib().orc_level_start(n, C.byref(s), C.byref(l))
