@@ -241,3 +241,40 @@ def test_otm_device_resident_request_equals_host_path():
     for d_ in (d_s, d_i, d_v, d_c):
         eng.dev_free(d_)
     eng.close()
+
+
+def test_long_history_forward_follows_training(oracle, fixture_w32):
+    """after an Adam step the general forward for L in 17..32 (din_forward_t, which reads plain transposes of
+    att.W / l1.W) must see the UPDATED matrices, like every other derived copy; and gradients accumulated over several
+    forward/backward calls before one Adam step keep every touched row (the touched-row list grows without losing entries)."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(31)
+    eng = Engine(0)
+    eng.load_weights_din(fixture_w32, 16, 8191)
+    eng.train_init(lr=5e-2)                    # a large step: stale matrices would be far outside the tolerance
+    touched = set()
+    for k, B in enumerate((40, 700, 90, 1500, 64, 333)):          # growing and shrinking batches, six accumulating calls
+        codes = rng.integers(1, 8191, B).astype(np.int32)
+        seqs = rng.integers(0, 8191, (B, 10)).astype(np.int32)
+        seqs[rng.random((B, 10)) < 0.2] = -1
+        pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+        eng.train_forward_backward(codes, seqs, pad, (rng.random(B) < 0.4).astype(np.float32))
+        touched |= set(codes.tolist()) | set(seqs[seqs >= 0].tolist())
+    import ctypes as C
+    from dismember_amd import _native as N
+    n = C.c_int64()
+    eng._chk(N.lib().dm_train_export_rows(eng._h, None, None, 0, C.byref(n)))
+    assert n.value == len(touched)                                  # nothing dropped, nothing duplicated
+    eng.adam_step()
+    w = eng.train_download("weights")
+    assert np.abs(w - fixture_w32).max() > 1e-2
+    for L in (20, 32, 10):
+        B = 64
+        codes = rng.integers(0, 8191, B).astype(np.int32)
+        seqs = rng.integers(0, 8191, (B, L)).astype(np.int32)
+        seqs[rng.random((B, L)) < 0.25] = -1
+        pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+        got = eng.din_forward(codes, seqs, pad)
+        ref = oracle.Din(w, 16, L, 8191).forward(codes, seqs, pad)
+        assert (np.abs(got - ref) <= 1e-5 + 1e-4 * np.abs(ref)).all(), L
+    eng.close()
