@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generates the JNI shim and the Scala `Native` object from include/dismember_hip.h, one native method per C entry point.
+
+    python tools/gen_jni.py            # rewrites jni/dismember_jni.c and scala/com/mass/hip/Native.scala
+    python tools/gen_jni.py --check    # exit 1 if the committed files differ from what the header yields
+
+tests/test_jni_shim.py runs the check (so the shim cannot drift from the header) and cross-checks the method set against
+dismember_amd/_native.SIGNATURES.  The reference reaches native code the same way (BigDL's MKL JNI,
+project/Dependencies.scala:27-29); nothing here is compiled in the build image (no JVM), the shim is compile-guarded on
+JAVA_HOME by jni/Makefile.
+
+Mapping: handle / communicator / device pointer -> jlong; `const T *` host arrays -> primitive arrays pinned with
+GetPrimitiveArrayCritical (released with JNI_ABORT when const, copied back otherwise; null allowed); `T *out` scalars ->
+arrays of length 1; option structs -> their fields as scalars; host `void *` buffers -> one method per element type;
+a non-zero status becomes the exception the Scala code would have thrown (raise()).
+"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "dismember_hip.h")
+OUT_C = os.path.join(ROOT, "jni", "dismember_jni.c")
+OUT_SCALA = os.path.join(ROOT, "scala", "com", "mass", "hip", "Native.scala")
+
+STRUCTS = {      # option structs flattened into scalars: (field, C type) in declaration order
+    "dm_tdm_search_opts": [("beam", "int"), ("topk", "int"), ("use_mask", "int"), ("widen_consumed", "int")],
+    "dm_adam_opts": [("lr", "double"), ("lr_decay", "double"), ("beta1", "double"), ("beta2", "double"), ("eps", "double")],
+    "dm_sample_opts": [("start_level", "int"), ("with_prob", "int"), ("tolerance", "int"), ("use_mask", "int"), ("seed", "uint64_t")],
+}
+SCALAR = {"int": ("jint", "Int"), "int32_t": ("jint", "Int"), "int64_t": ("jlong", "Long"), "uint64_t": ("jlong", "Long"),
+          "size_t": ("jlong", "Long"), "float": ("jfloat", "Float"), "double": ("jdouble", "Double")}
+ARRAY = {"int32_t": ("jintArray", "jint", "Array[Int]"), "int": ("jintArray", "jint", "Array[Int]"),
+         "uint32_t": ("jintArray", "jint", "Array[Int]"), "int64_t": ("jlongArray", "jlong", "Array[Long]"),
+         "uint64_t": ("jlongArray", "jlong", "Array[Long]"), "float": ("jfloatArray", "jfloat", "Array[Float]"),
+         "double": ("jdoubleArray", "jdouble", "Array[Double]"), "uint8_t": ("jbyteArray", "jbyte", "Array[Byte]")}
+# host `void *` arguments: entry point -> {arg: [(method suffix, element C type, extra fixed call args)]}
+VOID_HOST = {
+    "dm_load_weights_din": {"compact": [("F32", "float"), ("F64", "double")]},     # dtype is fixed by the variant (FIXED below)
+    "dm_din_forward": {"logits": [("F32", "float"), ("F64", "double")]},
+    "dm_comm_unique_id": {"id128": [("", "uint8_t")]},
+    "dm_comm_create_rccl": {"id128": [("", "uint8_t")]},
+    "dm_comm_all_gather_v": {"send": [("", "uint8_t")], "recv": [("", "uint8_t")]},
+    "dm_memcpy_h2d": {"src": [("", "uint8_t")]},
+    "dm_memcpy_d2h": {"dst": [("", "uint8_t")]},
+}
+FIXED = {("dm_load_weights_din", "F32"): {"dtype": "DM_F32"}, ("dm_load_weights_din", "F64"): {"dtype": "DM_F64"}}   # args the variant pins
+HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: written out below
+
+
+def camel(name):
+    parts = name[3:].split("_")
+    return parts[0] + "".join(p.capitalize() for p in parts[1:])
+
+
+def parse_header(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = []
+    for m in re.finditer(r"\b(int|const char \*)\s*(dm_\w+)\s*\(([^()]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        alist = []
+        if args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"^(const\s+)?([\w ]+?)\s*(\*\s*(?:const\s*)?\*?)?\s*(\w+)$", a)
+                const, base, ptr, an = bool(mm.group(1)), mm.group(2).strip(), (mm.group(3) or "").replace(" ", ""), mm.group(4)
+                alist.append(dict(const=const, base=base, ptr=ptr, name=an))
+        protos.append((ret, name, alist))
+    return protos
+
+
+def expand(protos):
+    """One or more (method name, C name, ret, args, void element type per arg) per prototype."""
+    out = []
+    for ret, name, args in protos:
+        if name in HANDWRITTEN:
+            continue
+        variants = [("", {})]
+        for an, vs in VOID_HOST.get(name, {}).items():
+            variants = [(s + suf, dict(d, **{an: ct})) for s, d in variants for suf, ct in vs]
+        # keep suffixes unique when two void args share the same element type
+        seen = {}
+        for suf, d in variants:
+            seen.setdefault(suf, d)
+        for suf, d in seen.items():
+            out.append((camel(name) + suf, name, ret, args, dict(d, __fixed__=FIXED.get((name, suf), {}))))
+    return out
+
+
+def gen(protos):
+    c, sc = [], []
+    for meth, cname, ret, args, voids in expand(protos):
+        jparams, sparams, pre, post, call = [], [], [], [], []
+        handle_expr = "0"
+        for i, a in enumerate(args):
+            base, ptr, an, const = a["base"], a["ptr"], a["name"], a["const"]
+            if an in voids.get("__fixed__", {}):
+                call.append(voids["__fixed__"][an])
+            elif base in ("dm_handle_t", "dm_comm_t") and ptr == "":
+                jparams.append("jlong %s" % an); sparams.append("%s: Long" % an)
+                call.append("(%s)(intptr_t)%s" % (base, an))
+                if base == "dm_handle_t" and i == 0:
+                    handle_expr = "(dm_handle_t)(intptr_t)%s" % an
+            elif base in ("dm_handle_t", "dm_comm_t") and ptr == "*":      # out handle(s) or a list of handles
+                jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
+                pre.append("  jlong *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (an, an, an))
+                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, 0);" % (an, an, an))
+                call.append("(%s *)p_%s" % (base, an))
+            elif base in STRUCTS and ptr == "*":
+                fields = STRUCTS[base]
+                for f, ct in fields:
+                    jparams.append("%s %s_%s" % (SCALAR[ct][0], an, f)); sparams.append("%s%s: %s" % (an, f.title().replace("_", ""), SCALAR[ct][1]))
+                pre.append("  %s s_%s = { %s };" % (base, an, ", ".join("(%s)%s_%s" % (ct, an, f) for f, ct in fields)))
+                call.append("&s_%s" % an)
+            elif base == "char" and ptr == "*":
+                jparams.append("jstring %s" % an); sparams.append("%s: String" % an)
+                pre.append("  const char *p_%s = %s ? (*e)->GetStringUTFChars(e, %s, 0) : 0;" % (an, an, an))
+                post.append("  if (p_%s) (*e)->ReleaseStringUTFChars(e, %s, p_%s);" % (an, an, an))
+                call.append("p_%s" % an)
+            elif base == "void" and ptr == "*" and an in voids:               # host buffer of a known element type
+                jt, je, st = ARRAY[voids[an]]
+                jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
+                pre.append("  %s *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (je, an, an, an))
+                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, %s);" % (an, an, an, "JNI_ABORT" if const else "0"))
+                call.append("p_%s" % an)
+            elif ptr in ("*", "**") and (base == "void" or an.startswith("d_") or an == "dptr"):   # device pointers travel as jlong
+                if ptr == "**" or (base != "void" and an in ("d_ptr",)) or an == "dptr":
+                    jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
+                    pre.append("  jlong *p_%s = (*e)->GetPrimitiveArrayCritical(e, %s, 0);" % (an, an))
+                    post.append("  (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, 0);" % (an, an))
+                    call.append("(%s %s)p_%s" % (base, ptr, an))
+                else:
+                    jparams.append("jlong %s" % an); sparams.append("%s: Long" % an)
+                    call.append("(%s%s *)(intptr_t)%s" % ("const " if const else "", base, an))
+            elif ptr == "*" and base in ARRAY:
+                jt, je, st = ARRAY[base]
+                jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
+                pre.append("  %s *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (je, an, an, an))
+                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, %s);" % (an, an, an, "JNI_ABORT" if const else "0"))
+                call.append("(%s%s *)p_%s" % ("const " if const else "", base, an))
+            elif ptr == "" and base in SCALAR:
+                jparams.append("%s %s" % (SCALAR[base][0], an)); sparams.append("%s: %s" % (an, SCALAR[base][1]))
+                call.append("(%s)%s" % (base, an))
+            else:
+                raise SystemExit("gen_jni: cannot map argument `%s %s%s` of %s" % (base, ptr, an, cname))
+        jret, sret = ("jstring", "String") if ret != "int" else (("jint", "Int") if cname in ("dm_version",) else ("void", "Unit"))
+        sig = "JNIEXPORT %s JNICALL Java_com_mass_hip_Native_%s(JNIEnv *e, jclass cls%s) {" % (jret, meth.replace("_", "_1"), "".join(", " + p for p in jparams))
+        body = [sig] + pre
+        callexpr = "%s(%s)" % (cname, ", ".join(call))
+        if ret != "int":
+            body.append("  const char *r_ = %s;" % callexpr)
+            body += post[::-1]
+            body.append("  (void)cls; return r_ ? (*e)->NewStringUTF(e, r_) : 0;")
+        elif jret == "jint":
+            body.append("  (void)e; (void)cls; return %s;" % callexpr)
+        else:
+            body.append("  const int rc_ = %s;" % callexpr)
+            body += post[::-1]
+            body.append("  (void)cls; if (rc_) raise(e, %s, rc_);" % handle_expr)
+        body.append("}")
+        c.append("\n".join(body))
+        sc.append("  @native def %s(%s): %s" % (meth, ", ".join(sparams), sret))
+    return c, sc
+
+
+C_HEAD = '''/* dismember_jni.c — JNI shim over include/dismember_hip.h: one native method of com.mass.hip.Native per C entry point.
+ * GENERATED by tools/gen_jni.py from the header — do not edit; `python tools/gen_jni.py --check` (tests/test_jni_shim.py)
+ * fails when this file and the header disagree.  Build (needs a JDK; the build image has none, see jni/Makefile):
+ *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include dismember_jni.c -L../dismember_amd -ldismember_hip -o libdismember_jni.so
+ * The reference binds its own native math the same way (BigDL MKL JNI, project/Dependencies.scala:27-29). */
+#include <jni.h>
+#include <stdint.h>
+
+#include "dismember_hip.h"
+
+/* a non-zero status becomes the exception the Scala code threw at that point */
+static void raise(JNIEnv *e, dm_handle_t h, int rc) {
+  const char *cls = rc == DM_ERR_INDEX ? "java/lang/ArrayIndexOutOfBoundsException"      /* LookupTable.scala:47-53 */
+                  : rc == DM_ERR_INVALID ? "java/lang/IllegalArgumentException"           /* require(...) */
+                  : rc == DM_ERR_STATE ? "java/lang/IllegalStateException"
+                  : rc == DM_ERR_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/RuntimeException";
+  const char *msg = dm_last_error(h);
+  (*e)->ThrowNew(e, (*e)->FindClass(e, cls), msg && *msg ? msg : "dismember_hip call failed");
+}
+'''
+
+C_DR = '''
+/* dm_dr_load_model: the struct carries per-layer arrays; the Scala side passes LayerModel / RerankModel storage arrays
+ * (deep-retrieval/.../model/DeepRetrieval.scala:90-106), fp64 like the reference */
+JNIEXPORT void JNICALL Java_com_mass_hip_Native_drLoadModelF64(JNIEnv *e, jclass cls, jlong h, jint embed, jint seqLen, jint numNode,
+    jint numLayer, jlong numItem, jdoubleArray layerEmb, jobjectArray layerW, jobjectArray layerB, jdoubleArray rerankEmb,
+    jdoubleArray rerankW, jdoubleArray rerankB, jdoubleArray softmaxW, jdoubleArray softmaxB) {
+  dm_dr_model m = {0};
+  const void *w[8] = {0}, *b[8] = {0};
+  jdoubleArray wa[8] = {0}, ba[8] = {0};
+  if (numLayer < 2 || numLayer > 8) { raise(e, (dm_handle_t)(intptr_t)h, DM_ERR_INVALID); return; }
+  m.dtype = DM_F64; m.on_device = 0; m.embed = embed; m.seq_len = seqLen; m.num_node = numNode; m.num_layer = numLayer; m.num_item = numItem;
+  for (int d = 0; d < numLayer; d++) {
+    wa[d] = (jdoubleArray)(*e)->GetObjectArrayElement(e, layerW, d); ba[d] = (jdoubleArray)(*e)->GetObjectArrayElement(e, layerB, d);
+    w[d] = (*e)->GetDoubleArrayElements(e, wa[d], 0); b[d] = (*e)->GetDoubleArrayElements(e, ba[d], 0);
+  }
+  m.layer_emb = (*e)->GetDoubleArrayElements(e, layerEmb, 0); m.layer_w = w; m.layer_b = b;
+  if (rerankEmb) {
+    m.rerank_emb = (*e)->GetDoubleArrayElements(e, rerankEmb, 0); m.rerank_w = (*e)->GetDoubleArrayElements(e, rerankW, 0);
+    m.rerank_b = (*e)->GetDoubleArrayElements(e, rerankB, 0); m.softmax_w = (*e)->GetDoubleArrayElements(e, softmaxW, 0);
+    m.softmax_b = (*e)->GetDoubleArrayElements(e, softmaxB, 0);
+  }
+  const int rc_ = dm_dr_load_model((dm_handle_t)(intptr_t)h, &m);
+  if (rerankEmb) {
+    (*e)->ReleaseDoubleArrayElements(e, softmaxB, (jdouble *)m.softmax_b, JNI_ABORT); (*e)->ReleaseDoubleArrayElements(e, softmaxW, (jdouble *)m.softmax_w, JNI_ABORT);
+    (*e)->ReleaseDoubleArrayElements(e, rerankB, (jdouble *)m.rerank_b, JNI_ABORT); (*e)->ReleaseDoubleArrayElements(e, rerankW, (jdouble *)m.rerank_w, JNI_ABORT);
+    (*e)->ReleaseDoubleArrayElements(e, rerankEmb, (jdouble *)m.rerank_emb, JNI_ABORT);
+  }
+  (*e)->ReleaseDoubleArrayElements(e, layerEmb, (jdouble *)m.layer_emb, JNI_ABORT);
+  for (int d = 0; d < numLayer; d++) {
+    (*e)->ReleaseDoubleArrayElements(e, ba[d], (jdouble *)b[d], JNI_ABORT); (*e)->ReleaseDoubleArrayElements(e, wa[d], (jdouble *)w[d], JNI_ABORT);
+  }
+  (void)cls; if (rc_) raise(e, (dm_handle_t)(intptr_t)h, rc_);
+}
+'''
+
+S_HEAD = '''// Native.scala — the JNI surface of libdismember_hip.so, one @native method per entry point of include/dismember_hip.h.
+// GENERATED by tools/gen_jni.py (do not edit).  Handles, communicators and device pointers are Long; a failing call throws
+// the exception the reference's Scala code threw at that point (jni/dismember_jni.c: raise).
+package com.mass.hip
+
+object Native {
+  System.loadLibrary("dismember_jni")
+
+'''
+S_DR = '''  @native def drLoadModelF64(h: Long, embed: Int, seqLen: Int, numNode: Int, numLayer: Int, numItem: Long, layerEmb: Array[Double],
+                             layerW: Array[Array[Double]], layerB: Array[Array[Double]], rerankEmb: Array[Double],
+                             rerankW: Array[Double], rerankB: Array[Double], softmaxW: Array[Double], softmaxB: Array[Double]): Unit
+'''
+
+
+def render():
+    protos = parse_header(open(HDR).read())
+    c, sc = gen(protos)
+    ctext = C_HEAD + "\n" + "\n\n".join(c) + "\n" + C_DR
+    stext = S_HEAD + "\n".join(sc) + "\n" + S_DR + "}\n"
+    return protos, ctext, stext
+
+
+def main():
+    protos, ctext, stext = render()
+    if "--check" in sys.argv:
+        ok = open(OUT_C).read() == ctext and open(OUT_SCALA).read() == stext
+        print("jni shim %s" % ("up to date" if ok else "OUT OF DATE: run python tools/gen_jni.py"))
+        return 0 if ok else 1
+    os.makedirs(os.path.dirname(OUT_C), exist_ok=True)
+    os.makedirs(os.path.dirname(OUT_SCALA), exist_ok=True)
+    open(OUT_C, "w").write(ctext)
+    open(OUT_SCALA, "w").write(stext)
+    print("wrote %s (%d entry points) and %s" % (os.path.relpath(OUT_C, ROOT), len(protos), os.path.relpath(OUT_SCALA, ROOT)))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
