@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <utility>
 #include <cerrno>
 #include <cfloat>
 #include <cmath>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "beam_kernel.hip.inc"
+#include "beam_kernel_w.hip.inc"
 #include "rows_kernel.hip.inc"
 #include "train_kernel.hip.inc"
 #include "dr_kernel.hip.inc"
@@ -57,8 +59,11 @@ struct dm_ctx {
   float b2 = 0.f;
   // split-fp16 scorer (dm_set_scorer_mode): fp16 hi/lo planes of W1a and the power-of-two scales, rebuilt lazily
   int scorer_mode = DM_SCORER_AUTO;
+  bool beam_w = false;         // split scorer on the one-wave-per-SIMD kernel (DM_BEAM_W=1 in the environment; default: the LDS-fed kernel)
   bool split_dirty = true;
   void *d_wsplit = nullptr;
+  void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)
+  size_t emb_split_bytes = 0;
   unsigned *d_maxabs = nullptr;
   int sh_e = 0, sh_w = 0;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
@@ -94,6 +99,8 @@ struct dm_ctx {
   void *d_samp = nullptr;
   size_t samp_bytes = 0;
   // multi-GPU exchange (comm.hip.inc): the attached communicator (not owned) and the staging area of dm_train_sync_gradients
+  void *d_defer = nullptr;       // users the W kernel hands to the LDS-fed kernel: [count u64 | queue head u64 | ids]
+  size_t defer_bytes = 0;
   struct dm_comm *comm = nullptr;
   void *d_sync = nullptr;
   size_t sync_bytes = 0;
@@ -267,6 +274,7 @@ int dm_create(int device_id, dm_handle_t *out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipGetDeviceProperties failed"); }
   h->n_cu = prop.multiProcessorCount;
+  { const char *e_ = getenv("DM_BEAM_W"); if (e_) h->beam_w = e_[0] == '1'; }
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipStreamCreate failed"); }
   if (hipMalloc((void **)&h->d_rows, 64) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
   (void)hipMemset(h->d_rows, 0, 64);
@@ -286,6 +294,7 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
+  dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
@@ -300,7 +309,7 @@ int dm_destroy(dm_handle_t h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
-  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp);
+  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -682,6 +691,7 @@ int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, con
 // ------------------------------------------------------------ beam search
 struct SearchPlan {
   int nteams, cap, pcap, grid, ws_cap, lds;
+  bool wkernel;        // the one-wave-per-SIMD kernel with W1a in the AccVGPRs (beam_kernel_w.hip.inc)
 };
 
 // the scorer arithmetic the beam kernels will use for this handle's model (dm_set_scorer_mode)
@@ -701,6 +711,13 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   while (pcap < cap) pcap <<= 1;
   const int kq = (L + 3) / 4;
   int nteams = 0;
+  pl->wkernel = false;
+  if (use_split(h) && h->beam_w) {
+    // split-fp16 scorer: one-wave teams, four per workgroup, W1a in registers; falls back when the frontier outgrows LDS
+    BeamWLds l = dm_beamw_lds(h->embed, cap, pcap, kq);
+    if (l.total <= 160 * 1024) { nteams = DMW_NWAVES; pl->lds = l.total; pl->wkernel = true; }
+  }
+  if (!nteams)
   for (int cand = 4; cand >= 1; cand >>= 1) {
     BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, use_split(h));
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
@@ -748,6 +765,28 @@ static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) 
   return DM_OK;
 }
 
+template <int E, int KQ>
+static int launch_beam_w_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_w_kernel<E, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  hipEvent_t e0, e1;
+  int rc = next_events(h, &e0, &e1);
+  if (rc != DM_OK) return rc;
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  hipLaunchKernelGGL((dm_beam_w_kernel<E, KQ>), dim3(pl.grid), dim3(DMW_BLOCK), pl.lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  return DM_OK;
+}
+template <int E>
+static int launch_beam_w_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  switch ((p.L + 3) / 4) {
+    case 1: return launch_beam_w_EK<E, 1>(h, p, pl);
+    case 2: return launch_beam_w_EK<E, 2>(h, p, pl);
+    case 3: return launch_beam_w_EK<E, 3>(h, p, pl);
+    default: return launch_beam_w_EK<E, 4>(h, p, pl);
+  }
+}
+
 template <int E, bool SPLIT>
 static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
   switch ((p.L + 3) / 4) {
@@ -785,6 +824,27 @@ __global__ void dm_build_wsplit_kernel(const float *wfrag, int E, float scale, _
   }
 }
 
+// The table as the one-wave-per-SIMD kernel gathers it: every fp32 value x already split into hi = RNE16(x 2^s) and
+// lo = RNE16(x 2^s - hi), laid out so that the lane group g of a tile finds, per row and k-step, its two MFMA B operands as 32
+// contiguous bytes: out[row][s][g][0..7] = hi of columns 32s + 16(i>>2) + 4g + (i&3), out[row][s][g][8..15] = lo of the same.
+// Same bytes per row as the fp32 table (E * 4); identical values to the split the LDS-fed kernel does per tile.
+__global__ void dm_build_emb_split_kernel(const float *emb, int64_t num_index, int E, float scale, _Float16 *out) {
+  const int64_t n8 = num_index * (int64_t)(E / 8);        // groups of 8 values = one (row, s, g)
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / (E / 8);
+    const int sg = (int)(t % (E / 8)), s_ = sg >> 2, g = sg & 3;
+    const float *src = emb + row * E + 32 * s_ + 4 * g;
+    _Float16 *dst = out + row * (int64_t)(2 * E) + (int64_t)sg * 16;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float x = src[16 * (i >> 2) + (i & 3)] * scale;
+      const _Float16 hi = (_Float16)x;
+      dst[i] = hi;
+      dst[8 + i] = (_Float16)(x - (float)hi);
+    }
+  }
+}
+
 // power-of-two shift that puts max|x| into [2^13, 2^14): every scaled value and every rounding of it stays below the fp16
 // maximum, and fp16 subnormals only start 2^27 below the largest element
 static int split_shift(unsigned maxbits) {
@@ -817,6 +877,18 @@ static int ensure_split(dm_ctx *h) {
   hipLaunchKernelGGL(dm_build_wsplit_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->d_wfrag, E, ldexpf(1.0f, h->sh_w),
                      (_Float16 *)h->d_wsplit);
   HIPCHK(h, hipGetLastError());
+  {
+    // the beam kernels gather pre-split rows: a second copy of the table (same size), rebuilt whenever the weights change
+    const size_t bytes = (size_t)h->num_index * E * 4;
+    if (h->emb_split_bytes != bytes) {
+      dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
+      ALLOC(h, h->d_emb_split, bytes);
+      h->emb_split_bytes = bytes;
+    }
+    hipLaunchKernelGGL(dm_build_emb_split_kernel, dim3(8192), dim3(256), 0, h->stream, h->d_emb32, h->num_index, E, ldexpf(1.0f, h->sh_e),
+                       (_Float16 *)h->d_emb_split);
+    HIPCHK(h, hipGetLastError());
+  }
   h->split_dirty = false;
   return DM_OK;
 }
@@ -829,8 +901,56 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
     int rc = ensure_split(h);
     if (rc != DM_OK) return rc;
     p.wsplit = (const dm_h8 *)h->d_wsplit;
+    p.emb_split = (const dm_h8 *)h->d_emb_split;
     p.emb_scale = ldexpf(1.0f, h->sh_e); p.score_unscale = ldexpf(1.0f, -2 * h->sh_e);
     p.acc_scale = ldexpf(1.0f, h->sh_e + h->sh_w); p.out_unscale = ldexpf(1.0f, -(h->sh_e + h->sh_w));
+    if (pl.wkernel) {
+      // users the W kernel cannot score in fp16 throughout are queued in [count | next | ids ...] and scored by the LDS-fed kernel
+      const size_t need = 16 + (size_t)p.U * 4;
+      if (h->defer_bytes < need) {
+        dm_free_ptr(h->d_defer); h->d_defer = nullptr; h->defer_bytes = 0;
+        ALLOC(h, h->d_defer, need + need / 4);
+        h->defer_bytes = need + need / 4;
+      }
+      HIPCHK(h, hipMemsetAsync(h->d_defer, 0, 16, h->stream));
+      p.defer_count = (unsigned long long *)h->d_defer;
+      p.defer_users = (int32_t *)((char *)h->d_defer + 16);
+      int rc = DM_OK;
+      switch (h->embed) {
+        case 32: rc = launch_beam_w_E<32>(h, p, pl); break;
+        case 64: rc = launch_beam_w_E<64>(h, p, pl); break;
+        default: rc = launch_beam_w_E<128>(h, p, pl); break;
+      }
+      if (rc != DM_OK) return rc;
+      // second pass (an empty list costs one launch): same parameters, the list as the work queue, its own frontier layout
+      SearchPlan pl2;
+      {
+        const int kq = (p.L + 3) / 4;
+        int nteams = 0;
+        for (int cand = 4; cand >= 1; cand >>= 1) {
+          BeamLds l = dm_beam_lds(h->embed, cand, pl.cap, pl.pcap, kq, true);
+          if (l.total <= 160 * 1024) { nteams = cand; pl2.lds = l.total; break; }
+        }
+        if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier");
+        pl2 = pl; pl2.nteams = nteams; pl2.wkernel = false;
+        BeamLds l = dm_beam_lds(h->embed, nteams, pl.cap, pl.pcap, kq, true);
+        pl2.lds = l.total;
+        // the workspace was sized for grid x 4 one-wave teams; the second pass may use at most as many (block, team) slots
+        if (pl2.grid * pl2.nteams > pl.grid * pl.nteams) pl2.grid = pl.grid * pl.nteams / pl2.nteams;
+        if (pl2.grid < 1) pl2.grid = 1;
+      }
+      BeamParams p2 = p;
+      p2.nteams = pl2.nteams;
+      p2.user_count = (const unsigned long long *)h->d_defer;
+      p2.user_list = (const int32_t *)((char *)h->d_defer + 16);
+      p2.next_user = (unsigned long long *)((char *)h->d_defer + 8);
+      p2.defer_count = nullptr; p2.defer_users = nullptr;
+      switch (h->embed) {
+        case 32: return launch_beam_E<32, true>(h, p2, pl2);
+        case 64: return launch_beam_E<64, true>(h, p2, pl2);
+        default: return launch_beam_E<128, true>(h, p2, pl2);
+      }
+    }
     switch (h->embed) {
       case 32: return launch_beam_E<32, true>(h, p, pl);
       case 64: return launch_beam_E<64, true>(h, p, pl);
@@ -1202,7 +1322,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
     p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws; p.ws_khi = (uint32_t *)h->d_ws; p.ws_klo = (uint32_t *)h->d_ws;
     p.ws_cap = 0;
     SearchPlan pl;
-    pl.nteams = nteams; pl.cap = cap; pl.pcap = pcap; pl.lds = lds; pl.ws_cap = 0;
+    pl.nteams = nteams; pl.cap = cap; pl.pcap = pcap; pl.lds = lds; pl.ws_cap = 0; pl.wkernel = false;
     int64_t groups = (n_work + nteams - 1) / nteams;
     pl.grid = (int)(groups < h->n_cu ? groups : h->n_cu);
     if ((rc = launch_beam(h, p, pl)) != DM_OK) break;
