@@ -59,7 +59,7 @@ struct dm_ctx {
   float b2 = 0.f;
   // split-fp16 scorer (dm_set_scorer_mode): fp16 hi/lo planes of W1a and the power-of-two scales, rebuilt lazily
   int scorer_mode = DM_SCORER_AUTO;
-  bool beam_w = false;         // split scorer on the one-wave-per-SIMD kernel (DM_BEAM_W=1 in the environment; default: the LDS-fed kernel)
+  bool beam_w = true;          // split scorer on the one-wave-per-SIMD kernel (beam_kernel_w.hip.inc); DM_BEAM_W=0 in the environment selects the LDS-fed kernel
   bool split_dirty = true;
   void *d_wsplit = nullptr;
   void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)

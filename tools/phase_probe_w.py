@@ -38,6 +38,9 @@ tiles = rows / 16.0
 print("cycles per tile in the tile loop: %.0f (matrix pipe minimum 124 x 16 = 1984)" % (v[4] / tiles))
 print("cycles per user outside the tile loop: %.0f" % ((v.sum() - v[4]) / U))
 tv = np.array(list(out)[8:16], dtype=np.float64)
-if tv.sum() > 0:
+if tv.sum() > 0 and os.environ.get("DM_PROBE_SETUP"):
+    print("setup sections (cycles per user, -DDM_SETUP_TIMERS): decode %.0f | K rows + split %.0f | T1 %.0f | G %.0f | G split %.0f | frontier %.0f"
+          % tuple(tv[:6] / U))
+elif tv.sum() > 0:
     print("tile sections (cycles per tile, -DDM_TILE_TIMERS): scores %.0f | W groups %s | PG %.0f | tail %.0f" %
           (tv[0] / tiles, " ".join("%.0f" % (x / tiles) for x in tv[1:3]), tv[3] / tiles, tv[4] / tiles))
