@@ -138,7 +138,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", LIB_PATH,
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", LIB_PATH,
            os.path.join(SRC_DIR, "dm_hip.hip"), "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"),
            "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
