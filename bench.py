@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""bench.py — TDM beam-search serving throughput on MI355X (BASELINE.json configs[1]).
+"""bench.py — TDM beam-search serving throughput on MI355X (BASELINE.json's metric: 10M-item tree, 1M users).
 
-Workload: synthetic 1M-item depth-20 binary tree, 128-d embeddings, DIN scorer, beam=200,
-topk=200, L=10 (SURVEY.md §8d "C2").  One step = one beam search over a batch of users whose
-histories are already resident in HBM.  N GPUs = N independent user shards (replicated table,
-no data-path collective; the barrier/max-over-ranks timing uses torch.distributed).
+Workload: synthetic 10M-item depth-24 binary tree, 128-d embeddings, DIN scorer, beam=200, topk=200, L=10
+(configs/c2_tdm_serve_1m.conf).  One step = one beam search over ONE shard of 131072 users whose
+histories are already resident in HBM; the steps cycle through 8 distinct shards (the 1M-user population).
+N GPUs = N independent user populations (replicated table, no data-path collective; the harness barrier uses
+torch.distributed, the slowest-rank clock dismember_amd.comm).
 
 Prints ONE JSON line (rank 0).
 """
@@ -25,14 +26,18 @@ PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, de
 PEAK_MFMA_F16_TFLOPS = 2516.6  # v_mfma_f32_16x16x32_f16: 16384 FLOP / 16 cycles / SIMD x 1024 SIMDs x 2.4 GHz (the guide's "~2.5 PF dense")
 
 
-def roofline(mode, rows, avg_ms, E, L):
+def roofline(mode, rows, avg_ms, E, L, kernel=None):
     """MFMA roofline of the beam kernel for one scorer arithmetic.  achieved = ALGORITHMIC flops of this formulation
-    (2(E^2 + 2LE + E) per scored row) / kernel time.  peak: fp32-input MFMA peak for the f32 mode; for the
-    split mode every product costs 3 fp16 MFMAs on padded 16x16x32 tiles, so the pipe's dense fp16 peak is scaled by
-    algorithmic / issued flops (the time the matrix pipe minimally needs per row is what bounds the kernel)."""
+    (2(E^2 + 2LE + E) per scored row) / the kernel's average launch duration (HIP events on its stream).
+    peak: fp32-input MFMA peak for the f32 mode; for the split mode every product costs 3 fp16 MFMAs on padded 16x16x32
+    tiles, so the pipe's dense fp16 peak is scaled by algorithmic / issued flops (the time the matrix pipe minimally
+    needs per row is what bounds the kernel).  Beside `frac` the split mode reports the plain fractions of the dense fp16
+    peak: issued (what the matrix pipe executes), useful (this formulation's flops) and the reference formulation's
+    (2(2LE + 3E^2 + E) per row — the reference recomputes the history projection per candidate)."""
     kq = (L + 3) // 4
     nt = E // 16
     flops_own = 2 * (E * E + 2 * L * E + E)
+    flops_ref = 2 * (2 * L * E + 3 * E * E + E)
     t = avg_ms * 1e-3
     ach = rows * flops_own / t / 1e12
     if mode == "f32":
@@ -43,12 +48,17 @@ def roofline(mode, rows, avg_ms, E, L):
         ns = E // 32
         issued = (3 * ns + 2 * nt + 3 * ns * nt) * 16384 / 16.0              # 3 x S^T + 2 x (P x G) + 3 x main chain, 16x16x32
         peak = PEAK_MFMA_F16_TFLOPS * flops_own / issued
-        extra = {"mfma_issued_tflops_f16": rows * issued / t / 1e12, "f16_dense_peak_tflops": PEAK_MFMA_F16_TFLOPS,
+        iss_t = rows * issued / t / 1e12
+        extra = {"mfma_issued_tflops_f16": iss_t, "f16_dense_peak_tflops": PEAK_MFMA_F16_TFLOPS,
+                 "issued_frac_of_fp16_peak": iss_t / PEAK_MFMA_F16_TFLOPS,
+                 "useful_frac_of_fp16_peak": ach / PEAK_MFMA_F16_TFLOPS,
                  "issued_per_algorithmic_flop": issued / flops_own,
                  "peak_note": "fp16 dense peak x algorithmic/issued flops: 3 fp16 MFMAs per product (hi*hi + hi*lo + lo*hi; 2 for the attention-combine product) on 16x16x32 tiles"}
     r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-         "kernel": "dm_beam_kernel<%d, %d, %s>" % (E, kq, "true" if mode != "f32" else "false"), "kernel_ms_avg": avg_ms,
-         "flops_per_row_algorithmic": flops_own}
+         "kernel": kernel or ("dm_beam_kernel<%d, %d, %s>" % (E, kq, "true" if mode != "f32" else "false")), "kernel_ms_avg": avg_ms,
+         "flops_per_row_algorithmic": flops_own,
+         "reference_formulation_flops_per_row": flops_ref,
+         "reference_formulation_tflops": rows * flops_ref / t / 1e12}
     r.update(extra)
     return r
 PEAK_HBM_GBPS = 8000.0
@@ -59,13 +69,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--users", type=int, default=131072, help="users per step per GPU (x 8-10 steps = the 1M-user population of the target)")
+    ap.add_argument("--users", type=int, default=131072, help="users per step (= per shard) per GPU")
+    ap.add_argument("--shards", type=int, default=8, help="distinct user shards the steps cycle through (8 x 131072 = the 1M-user population of the target)")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--depth", type=int, default=24)
-    ap.add_argument("--embed", type=int, default=128)
-    ap.add_argument("--beam", type=int, default=200)
-    ap.add_argument("--topk", type=int, default=200)
-    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--conf", default=os.path.join(ROOT, "configs", "c2_tdm_serve_1m.conf"),
+                    help="TDMTrainDeepModel .conf the serving / training parameters come from (reference format, dismember_amd/conf.py)")
+    ap.add_argument("--dr-conf", default=os.path.join(ROOT, "configs", "c5_dr_10m.conf"), help="DeepRetrieval .conf of the Deep-Retrieval extra")
+    ap.add_argument("--embed", type=int, default=None, help="override model.embed_size")
+    ap.add_argument("--beam", type=int, default=None, help="override model.beam_size")
+    ap.add_argument("--topk", type=int, default=None, help="override model.topk_number")
+    ap.add_argument("--seq-len", type=int, default=None, help="override model.seq_len")
     ap.add_argument("--cpu-users", type=int, default=-1, help="oracle sample size (-1 auto, 0 skip)")
     ap.add_argument("--rho", type=float, default=0.95, help="parent-child correlation of the synthetic node embeddings")
     ap.add_argument("--train", type=int, default=1, help="also time a training step (0 = skip)")
@@ -75,10 +89,17 @@ def parse():
     ap.add_argument("--scorer", default="auto", choices=["auto", "f32", "split_f16"],
                     help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode; auto = the library default)")
     ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
-    ap.add_argument("--recall-users", type=int, default=64, help="users for recall@topk vs brute force (0 skip)")
+    ap.add_argument("--recall-users", type=int, default=1024, help="users for recall@topk vs brute force (0 skip)")
     a = ap.parse_args()
     if a.big is not None:
         a.small = a.big
+    from dismember_amd import conf as dmconf
+    a.params = dmconf.task_params("TDMTrainDeepModel", a.conf)
+    a.embed = a.embed or a.params["embed_size"]
+    a.beam = a.beam or a.params["beam_size"]
+    a.topk = a.topk or a.params["topk_number"]
+    a.seq_len = a.seq_len or a.params["seq_len"]
+    a.dr_params = dmconf.read_conf(a.dr_conf, "model")
     return a
 
 
@@ -130,11 +151,19 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
                        tree["max_level"])
     din = po.Din(w, E, L, num_index)
     cores = effective_cores()
-    if n_users <= 0:                                   # auto: aim at ~15 s of wall time on all cores
-        t0 = time.perf_counter()
-        otree.recommend_batch(din, seqs[:2], topk, beam, n_threads=1)
-        per_user = (time.perf_counter() - t0) / 2
-        n_users = int(max(cores, min(16384, 15.0 * cores / max(per_user, 1e-6))))
+    t0 = time.perf_counter()
+    otree.recommend_batch(din, seqs[:2], topk, beam, n_threads=1)
+    per_user = (time.perf_counter() - t0) / 2
+    # one core first: ~6 s of the same users on ONE thread (the reference's per-thread rate, T/evaluation/Evaluator.scala runs one
+    # such loop per core)
+    n1 = int(max(4, min(seqs.shape[0], 6.0 / max(per_user, 1e-6))))
+    t0 = time.perf_counter()
+    otree.recommend_batch(din, seqs[:n1], topk, beam, n_threads=1)
+    dt1 = time.perf_counter() - t0
+    one = dict(value=n1 / dt1, unit="users/s", cores=1, kind="port",
+               sample="the first %d users of the same workload on one thread, %.1f s wall, oracle/libdm_oracle.so" % (n1, dt1))
+    if n_users <= 0:                                   # auto: aim at ~12 s of wall time on all cores
+        n_users = int(max(cores, min(16384, 12.0 * cores / max(per_user, 1e-6))))
     n_users = min(n_users, seqs.shape[0])
     cores = min(cores, n_users)
     t0 = time.perf_counter()
@@ -142,7 +171,7 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
     dt = time.perf_counter() - t0
     return dict(value=n_users / dt, unit="users/s", cores=cores, kind="port",
                 sample="%d users of the same workload, %.1f s wall, oracle/libdm_oracle.so (C restatement of the "
-                       "reference path, one pthread per usable core (cgroup quota) over contiguous user ranges)" % (n_users, dt)), (ids, cnt)
+                       "reference path, one pthread per usable core (cgroup quota) over contiguous user ranges)" % (n_users, dt)), one, (ids, cnt)
 
 
 def init_distributed():
@@ -176,8 +205,10 @@ def main():
     num_index = (1 << (depth + 1)) - 1
     rng = np.random.default_rng(synth.SEED)
     tree = synth.make_tree(a.items, depth, rng)
-    urng = np.random.default_rng(synth.SEED + 1 + rank)       # every rank: its own user shard
-    seqs = synth.make_users(tree["leaf_ids"], a.users, L, urng)
+    # every rank: its own population of `shards` x `users` users (rank-dependent seeds), one device buffer per shard
+    NSH = max(1, a.shards)
+    shard_seqs = [synth.make_users(tree["leaf_ids"], a.users, L, np.random.default_rng(synth.SEED + 1 + rank + 1000 * k)) for k in range(NSH)]
+    seqs = shard_seqs[0]
 
     eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))   # override only for single-GPU smoke tests of the N>1 path
     eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth)
@@ -187,11 +218,15 @@ def main():
     eng.load_weights_din_synthetic(E, num_index, synth.SEED, tree_depth=depth, rho=a.rho)
 
     U = a.users
-    d_seq = eng.dev_alloc(U * L * 4)
+    d_seqs = []
+    for k in range(NSH):
+        d_ = eng.dev_alloc(U * L * 4)
+        eng.h2d(d_, shard_seqs[k])
+        d_seqs.append(d_)
+    d_seq = d_seqs[0]
     d_ids = eng.dev_alloc(U * a.topk * 4)
     d_sc = eng.dev_alloc(U * a.topk * 4)
     d_cnt = eng.dev_alloc(U * 4)
-    eng.h2d(d_seq, seqs)
 
     def sync():
         eng.synchronize()
@@ -203,20 +238,31 @@ def main():
             dist.barrier()
 
     eng.set_scorer_mode(a.scorer)
-    for _ in range(a.warmup):
-        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+    # untimed: one pass per shard records its scored-row count (the roofline's work figure) and builds the scorer's planes
+    shard_rows = []
+    for k in range(NSH):
+        eng.tdm_beam_search_dev(d_seqs[k], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync()
+        shard_rows.append(eng.last_scored_rows())
+    for i in range(a.warmup):
+        eng.tdm_beam_search_dev(d_seqs[i % NSH], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync()
     eng.timing_reset()
     barrier(); sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+    for i in range(a.steps):
+        eng.tdm_beam_search_dev(d_seqs[i % NSH], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync(); barrier()
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, comm)
-    n_launch, kernel_ms = eng.timing_get()
-    rows = eng.last_scored_rows()                    # scored (node, user) rows of ONE step
+    n_launch, kernel_ms = eng.timing_get_kind(0)                # the search kernel proper (HIP events on the library's stream)
+    n_defer, defer_ms = eng.timing_get_kind(1)                  # second pass over deferred users (one-wave kernel only)
+    kern_name = eng.last_beam_kernel()
+    rows = sum(shard_rows[i % NSH] for i in range(a.steps)) / float(a.steps)     # scored (node, user) rows per step, averaged over the timed steps
 
+    # results of shard 0 (recall, the CPU oracle's comparison and the other-scorer comparison all use shard 0)
+    eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+    sync()
     ids = np.empty((U, a.topk), np.int32)
     sc = np.empty((U, a.topk), np.float32)
     cnt = np.empty(U, np.int32)
@@ -237,7 +283,8 @@ def main():
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
         dto_ = sharding.max_over_ranks(time.perf_counter() - t0, comm)
-        nlo_, kmo_ = eng.timing_get()
+        nlo_, kmo_ = eng.timing_get_kind(0)
+        kern_o = eng.last_beam_kernel()
         ids_o = np.empty((U, a.topk), np.int32); sc_o = np.empty((U, a.topk), np.float32); cnt_o = np.empty(U, np.int32)
         eng.d2h(ids_o, d_ids); eng.d2h(sc_o, d_sc); eng.d2h(cnt_o, d_cnt)
         if omode == "split_f16":
@@ -245,10 +292,10 @@ def main():
         eng.set_scorer_mode(a.scorer)
         same_rows = (ids_o == ids).all(axis=1) & (cnt_o == cnt)
         dsc = np.abs(sc_o[same_rows].astype(np.float64) - sc[same_rows])
-        other = {"mode": omode, "what": "the same search (engine, users, beam logic) with the other scorer arithmetic "
+        other = {"mode": omode, "what": "the same search (engine, shard 0 of the users, beam logic) with the other scorer arithmetic "
                                         "(include/dismember_hip.h: dm_set_scorer_mode)",
                  "users_per_s": world * U * n_o / dto_, "ms_per_step": dto_ / n_o * 1e3, "steps": n_o,
-                 "roofline": roofline(omode, rows, kmo_ / max(nlo_, 1), E, L),
+                 "roofline": roofline(omode, shard_rows[0], kmo_ / max(nlo_, 1), E, L, kern_o),
                  "headline_speedup_over_this": (dto_ / n_o) / (dt / a.steps),
                  "identical_id_lists_vs_headline": "%d/%d" % (int(same_rows.sum()), U),
                  "max_abs_score_diff_on_identical_lists": float(dsc.max()) if dsc.size else None,
@@ -256,11 +303,9 @@ def main():
 
     if rank == 0:
         avg_ms = kernel_ms / max(n_launch, 1)
-        flops_ref = 2 * (2 * L * E + 3 * E * E + E)                 # SURVEY.md §8d, reference formulation
-        roof = roofline(mode, rows, avg_ms, E, L)
-        roof.update({"launches": n_launch, "reference_formulation_flops_per_row": flops_ref,
-                     "reference_formulation_tflops": rows * flops_ref / (avg_ms * 1e-3) / 1e12,
-                     "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9})
+        roof = roofline(mode, rows, avg_ms, E, L, kern_name)
+        roof.update({"launches": n_launch, "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9,
+                     "second_pass_ms_avg": (defer_ms / n_defer) if n_defer else 0.0})
         res = {
             "metric": "beam-search users/sec + recall@200 vs brute-force, 10M-item tree" if a.items == 10_000_000 else
                       "beam-search users/sec (TDM serve, %d-item depth-%d tree, %d-d, beam %d)" % (a.items, depth, E, a.beam),
@@ -273,7 +318,8 @@ def main():
             "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
                                    "beam=%d, topk=%d, L=%d, 1xMI355X per shard (the catalogue BASELINE.json's metric names; 17.2 GB table)"
                                    % (a.items, depth, E, a.beam, a.topk, L),
-                       "users_per_step_per_gpu": U, "parallelism": "user-sharded x%d, replicated table" % world,
+                       "users_per_step_per_gpu": U, "user_shards": NSH, "distinct_users_per_gpu": U * NSH,
+                       "parallelism": "user-sharded x%d, replicated table" % world,
                        "scored_rows_per_user": rows / U},
             "roofline": roof,
             "scorer": {"mode": mode, "shift_emb": info["shift_emb"], "shift_w": info["shift_w"]},
@@ -282,13 +328,17 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01f_summary.json" if mode != "f32" else "r01e_summary.json")))
+            pname = "r02_summary.json" if mode != "f32" else "r02_f32_summary.json"
+            prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
             pw = prof["bench_line_under_profiler"]["config"]
-            if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U:
+            if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U and prof["kernel_trace"]["kernel"].startswith(kern_name.split("<")[0]):
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
-                res["roofline"]["traffic_source"] = ("profiles/r01%s_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                     "(separate passes), bytes per launch, FETCH x2 gfx950 correction") % ("f" if mode != "f32" else "e")
+                res["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch, "
+                                                     "FETCH x2 gfx950 correction (MI355X_MICROARCH.md)") % pname
                 res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
+                res["roofline"]["profiled_kernel_ms_avg"] = prof["kernel_trace"]["avg_ns"] / 1e6
+                if "mfma_pipe_utilisation" in prof:
+                    res["roofline"]["profiled_mfma_busy_frac"] = prof["mfma_pipe_utilisation"]
         except Exception:
             pass
         if a.recall_users > 0:
@@ -305,8 +355,9 @@ def main():
         elif world == 1 and a.cpu_users != 0:
             n_cpu = a.cpu_users
             w = eng.download_weights()
-            base, outs = cpu_baseline(tree, w, E, L, num_index, seqs, a.beam, a.topk, n_cpu)
+            base, one, outs = cpu_baseline(tree, w, E, L, num_index, seqs, a.beam, a.topk, n_cpu)
             res["cpu_baseline"] = base
+            res["cpu_baseline_1core"] = one
             oids, ocnt = outs
             same = sum(int(cnt[u] == ocnt[u] and np.array_equal(ids[u, :cnt[u]], oids[u, :ocnt[u]]))
                        for u in range(len(ocnt)))
@@ -361,7 +412,9 @@ def main():
     # ---- extra: BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel training step on it ----
     small = train = None
     if a.small and default_cfg:
-        eng.dev_free(d_seq); eng.dev_free(d_ids); eng.dev_free(d_sc); eng.dev_free(d_cnt)
+        for d_ in d_seqs:
+            eng.dev_free(d_)
+        eng.dev_free(d_ids); eng.dev_free(d_sc); eng.dev_free(d_cnt)
         eng.close()
         depth2, items2 = 20, 1_000_000
         ni2 = (1 << (depth2 + 1)) - 1
@@ -383,14 +436,14 @@ def main():
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
         dt2 = sharding.max_over_ranks(time.perf_counter() - t0, comm)
-        nl2, kms2 = eng.timing_get()
+        nl2, kms2 = eng.timing_get_kind(0)
         rows2 = eng.last_scored_rows()
         small = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (BASELINE.json configs[1])"
                              % (items2, depth2, E, a.beam, a.topk),
                  "users_per_s": world * U * nst / dt2, "steps": nst, "ms_per_step": dt2 / nst * 1e3,
                  "scored_rows_per_user": rows2 / U,
                  "scorer": eng.scorer_mode()["mode"],
-                 "roofline_frac": roofline(eng.scorer_mode()["mode"], rows2, kms2 / max(nl2, 1), E, L)["frac"]}
+                 "roofline_frac": roofline(eng.scorer_mode()["mode"], rows2, kms2 / max(nl2, 1), E, L, eng.last_beam_kernel())["frac"]}
         if rank == 0:
             ids2 = np.empty((U, a.topk), np.int32); cnt2 = np.empty(U, np.int32)
             eng.d2h(ids2, d_ids); eng.d2h(cnt2, d_cnt)
@@ -401,17 +454,19 @@ def main():
                     [len(set(ids2[u, :cnt2[u]].tolist()) & set(bids[u, :bcnt[u]].tolist())) / float(a.topk) for u in range(nr)]))
                 small["recall_users"] = nr
             if world == 1 and a.cpu_users != 0 and "cpu_baseline" not in res_main:
-                base, outs = cpu_baseline(tree2, eng.download_weights(), E, L, ni2, seqs2, a.beam, a.topk, a.cpu_users)
+                base, one, outs = cpu_baseline(tree2, eng.download_weights(), E, L, ni2, seqs2, a.beam, a.topk, a.cpu_users)
+                small["cpu_baseline_1core"] = one
                 oids, ocnt = outs
                 same = sum(int(cnt2[u] == ocnt[u] and np.array_equal(ids2[u, :cnt2[u]], oids[u, :ocnt[u]])) for u in range(len(ocnt)))
                 base["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
                 small["cpu_baseline"] = base
         if a.train:
             from dismember_amd.trainer import TDMTrainer
-            neg = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 19, 22, 25, 30], np.int32)   # configs/tdm.conf
+            neg = np.array(a.params["layer_negative_counts_list"], np.int32)            # model.layer_negative_counts
             per = int(sum(1 + neg[l] for l in range(1, depth2 + 1)))
-            Tt = max(1, 8192 // per)                        # total_batch_size 8192 expanded rows per worker
-            tr = TDMTrainer(eng, neg, lr=1e-4, comm=comm, seed=synth.SEED, sampler="host")
+            Tt = max(1, a.params["total_batch_size"] // per)                # model.total_batch_size expanded rows per worker
+            tr = TDMTrainer(eng, neg, lr=a.params["learning_rate"], comm=comm, seed=synth.SEED, sampler="device",
+                            with_prob=a.params["sample_with_probability"])
             trng = np.random.default_rng(synth.SEED + 7 + rank)
             tseq = synth.make_users(tree2["leaf_ids"], Tt, L, trng)
             ttgt = trng.choice(tree2["leaf_ids"], Tt).astype(np.int32)
@@ -424,55 +479,73 @@ def main():
             sync(); barrier()
             dtt = sharding.max_over_ranks(time.perf_counter() - t0, comm)
             nparam = ni2 * E + 3 * E * E + 2 * E + 1
-            train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives), "
-                                 "DIN fwd+bwd, gradient exchange, dense Adam over %d parameters" % (Tt, Tt * per, nparam),
+            train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives drawn on the device), "
+                                 "DIN fwd+bwd, gradient exchange (dm_train_sync_gradients: RCCL inside the library), dense Adam over %d parameters" % (Tt, Tt * per, nparam),
                      "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
                      "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world}
-    # ---- extra: Deep-Retrieval serving, BASELINE config 5 (row A13): D=3, K=1000, beam=50, 10M items ----
+    # ---- extra: Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=1000, beam=50, 10M items.  The record is the fp64
+    #      run (the reference's arithmetic type, deep-retrieval/.../model/LayerModel.scala); the f32 model with the split-fp16
+    #      history GEMM is timed beside it on the same inputs ----
     dr = None
     if a.dr and default_cfg:
         eng.close()
-        eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
-        Kd, Dd, beam_d, topk_d, items_d, Ud = 1000, 3, 50, 10, 10_000_000, 16384
-        eng.dr_load_model_synthetic(E, L, Kd, Dd, items_d, synth.SEED, scale=0.05, rerank=True)
+        dp = a.dr_params
+        Kd, Dd, beam_d, topk_d = int(dp["num_node"]), int(dp["num_layer"]), int(dp["beam_size"]), int(dp["topk_number"])
+        Ld, Ed, Jd = int(dp["seq_len"]), int(dp["embed_size"]), int(dp["num_path_per_item"])
+        items_d, Ud = 10_000_000, 16384
         drng = np.random.default_rng(synth.SEED + 303 + rank)
-        dseq = drng.integers(0, items_d, size=(Ud, L)).astype(np.int32)
-        dseq[drng.random((Ud, L)) < 0.15] = -1
-        eng.dr_load_path_items(*synth.dr_path_items_fast(synth.make_dr_paths(items_d, Kd, Dd, 2, np.random.default_rng(synth.SEED)), Kd))
-        q_seq = eng.dev_alloc(Ud * L * 4); eng.h2d(q_seq, dseq)
-        q_paths = eng.dev_alloc(Ud * beam_d * Dd * 4); q_probs = eng.dev_alloc(Ud * beam_d * 8); q_cnt = eng.dev_alloc(Ud * 4)
-        q_ids = eng.dev_alloc(Ud * topk_d * 4); q_sc = eng.dev_alloc(Ud * topk_d * 8)
+        dseq = drng.integers(0, items_d, size=(Ud, Ld)).astype(np.int32)
+        dseq[drng.random((Ud, Ld)) < 0.15] = -1
+        path_items = synth.dr_path_items_fast(synth.make_dr_paths(items_d, Kd, Dd, Jd, np.random.default_rng(synth.SEED)), Kd)
         nsd = max(2, a.steps // 2)
-        eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
-        sync(); eng.timing_reset(); barrier(); sync()
-        t0 = time.perf_counter()
-        for _ in range(nsd):
+        runs = {}
+        for tag, dtp in (("f64", np.float64), ("f32", np.float32)):
+            eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+            eng.dr_load_model_synthetic(Ed, Ld, Kd, Dd, items_d, synth.SEED, scale=0.05, rerank=True, dtype=dtp)
+            eng.dr_load_path_items(*path_items)
+            q_seq = eng.dev_alloc(Ud * Ld * 4); eng.h2d(q_seq, dseq)
+            q_paths = eng.dev_alloc(Ud * beam_d * Dd * 4); q_probs = eng.dev_alloc(Ud * beam_d * 8); q_cnt = eng.dev_alloc(Ud * 4)
+            q_ids = eng.dev_alloc(Ud * topk_d * 4); q_sc = eng.dev_alloc(Ud * topk_d * 8)
             eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
-        sync(); barrier()
-        dtb = sharding.max_over_ranks(time.perf_counter() - t0, comm)
-        _, kms_b = eng.timing_get()
-        eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
-        sync(); barrier(); sync()
-        t0 = time.perf_counter()
-        for _ in range(nsd):
+            sync(); eng.timing_reset(); barrier(); sync()
+            t0 = time.perf_counter()
+            for _ in range(nsd):
+                eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
+            sync(); barrier()
+            dtb = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+            _, kms_b = eng.timing_get()
+            paths_h = np.empty((Ud, beam_d, Dd), np.int32)
+            eng.d2h(paths_h, q_paths)
             eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
-        sync(); barrier()
-        dtr = sharding.max_over_ranks(time.perf_counter() - t0, comm)
-        # per user: 3 history GEMM rows of K x L*E (the only matrix work left) + (1 + 50 + 50) table-row sums of K
-        table_bytes = (beam_d * 1 + beam_d * 2) * Kd * 4
-        dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x 2 paths, %d-d, f32 model, history GEMM in the split-fp16 arithmetic (reference computes in f64)"
-                          % (Dd, Kd, beam_d, items_d, E),
-              "beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
-              "beam_search_kernel_ms_per_step": kms_b / nsd,
-              "recommend_users_per_s": world * Ud * nsd / dtr, "users_per_step": Ud, "steps": nsd,
-              "gemm_flop_per_user": 2 * Dd * Kd * L * E, "table_row_bytes_per_user": table_bytes,
-              "reference_formulation_flop_per_user": 2 * Kd * E * (L + beam_d * (L + 1) + beam_d * (L + 2))}
+            sync(); barrier(); sync()
+            t0 = time.perf_counter()
+            for _ in range(nsd):
+                eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
+            sync(); barrier()
+            dtr = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+            runs[tag] = {"beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
+                         "beam_search_kernel_ms_per_step": kms_b / nsd, "recommend_users_per_s": world * Ud * nsd / dtr,
+                         "paths": paths_h}
+            eng.close()
+        eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))       # the later sections expect a live engine to close
+        same_paths = int((runs["f64"]["paths"] == runs["f32"]["paths"]).all(axis=(1, 2)).sum())
+        for r_ in runs.values():
+            del r_["paths"]
+        # per user: D history GEMM rows of K x L*E (the only matrix work left) + (1 + beam + beam) table-row sums of K
+        dr = {"workload": "Deep-Retrieval serving, D=%d K=%d beam=%d, %d items x %d paths, %d-d (configs/c5_dr_10m.conf), fp64 model and arithmetic "
+                          "(the reference's type); f32_split = the same draws as an f32 model, history GEMM in the split-fp16 arithmetic"
+                          % (Dd, Kd, beam_d, items_d, Jd, Ed),
+              "dtype": "f64", "users_per_step": Ud, "steps": nsd,
+              "f32_split": runs["f32"], "f32_users_with_identical_path_lists": "%d/%d" % (same_paths, Ud),
+              "gemm_flop_per_user": 2 * Dd * Kd * Ld * Ed, "table_row_bytes_per_user_f64": (beam_d * 1 + beam_d * 2) * Kd * 8,
+              "reference_formulation_flop_per_user": 2 * Kd * Ed * (Ld + beam_d * (Ld + 1) + beam_d * (Ld + 2))}
+        dr.update(runs["f64"])
         if rank == 0 and a.cpu_users != 0:
             from oracle import pyoracle as po
             small_items = 20000
-            wsm = synth.make_dr_model(small_items, Kd, Dd, L, E, np.random.default_rng(1), scale=0.05)
-            orc = po.DeepRetrieval(wsm, E, L, Kd, Dd, small_items)
-            cs = np.random.default_rng(2).integers(0, small_items, size=(24, L)).astype(np.int32)
+            wsm = synth.make_dr_model(small_items, Kd, Dd, Ld, Ed, np.random.default_rng(1), scale=0.05)
+            orc = po.DeepRetrieval(wsm, Ed, Ld, Kd, Dd, small_items)
+            cs = np.random.default_rng(2).integers(0, small_items, size=(24, Ld)).astype(np.int32)
             orc.beam_search(cs[0], beam_d)
             t0 = time.perf_counter()
             for r_ in cs:
@@ -507,10 +580,21 @@ def main():
             for _ in range(100):
                 oi1, _ol = ot1.recommend(od1, q1, 10, 20)
             dto1 = (time.perf_counter() - t0) / 100
+            # recall of the beam against brute force on the TRAINED model, the reference's own serving parameters (beam 20, topk 10)
+            # and the bench's (beam = topk = 200), 2048 synthetic users over the bundled catalogue
+            q1s = synth.make_users(t1["leaf_ids"], 2048, 10, np.random.default_rng(synth.SEED + 909))
+            rec1 = {}
+            for bm_, tk_ in ((20, 10), (200, 200)):
+                bi_, _, bc_ = e1.tdm_beam_search(q1s, bm_, tk_)
+                fi_, _, fc_ = e1.tdm_bruteforce_topk(q1s, tk_)
+                rec1["beam%d_top%d" % (bm_, tk_)] = float(np.mean([len(set(bi_[u, :bc_[u]].tolist()) & set(fi_[u, :fc_[u]].tolist())) / float(min(tk_, max(1, fc_[u])))
+                                                                 for u in range(len(q1s))]))
             c1 = {"workload": "BASELINE configs[0] serving timer: bundled trained E=16 DIN + depth-12 tree (3706 items), TDM.recommend(query, topk=10, "
                               "candidateNum=20), one user per call, 10 warm-up + 100 timed calls",
                   "ms_per_call": dt1 * 1e3, "cpu_oracle_ms_per_call": dto1 * 1e3, "cpu_oracle": "oracle/libdm_oracle.so, 1 thread",
-                  "same_items_as_oracle": sorted(r_[0] for r_ in recs1) == sorted(oi1.tolist())}
+                  "same_items_as_oracle": sorted(r_[0] for r_ in recs1) == sorted(oi1.tolist()),
+                  "recall_vs_bruteforce_trained_model": dict(rec1, users=len(q1s),
+                                                             definition="|beam top-k  ∩  brute-force top-k| / k on the bundled trained DIN (tests/golden/din_f32.npy)")}
             e1.close()
         except Exception as ex:       # the fixtures are test data: their absence must not break the bench line
             c1 = {"skipped": repr(ex)}

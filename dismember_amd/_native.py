@@ -100,6 +100,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dm_otm_beam_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dm_fill_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
+    "dm_fill_normal_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
     "dm_fill_tree_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64]),
     "dm_load_weights_din_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "dm_set_scorer_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -123,6 +124,8 @@ SIGNATURES = {
     "dm_allreduce_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
     "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dm_last_beam_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "dm_kernel_timing_get_kind": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dm_last_scored_rows": (C.c_int, [C.c_void_p, i64p]),
 }
 

@@ -80,6 +80,9 @@ struct dm_ctx {
   // measurement
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  std::vector<int> ev_kind;    // per pair: 0 = a main kernel, 1 = the second pass over the users the one-wave kernel deferred
+  int ev_next_kind = 0;
+  char last_kernel[64] = "";   // the search kernel of the last beam search (measurement: dm_last_beam_kernel)
   unsigned long long *d_rows = nullptr;
   unsigned long long *d_phase = nullptr;   // 8 debug counters
   int64_t last_rows = 0;
@@ -524,7 +527,8 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
   return DM_OK;
 }
 
-__global__ void dm_fill_normal_kernel(float *out, int64_t n, float mean, float std, unsigned long long seed) {
+template <typename T>
+__global__ void dm_fill_normal_kernel(T *out, int64_t n, float mean, float std, unsigned long long seed) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
   for (; i < n; i += stride) {
@@ -537,8 +541,8 @@ __global__ void dm_fill_normal_kernel(float *out, int64_t n, float mean, float s
     const float r = sqrtf(-2.0f * logf(u1));
     float sn, cs;
     sincosf(6.2831853071795864f * u2, &sn, &cs);
-    out[i] = mean + std * r * cs;
-    if (i + 1 < n) out[i + 1] = mean + std * r * sn;
+    out[i] = (T)(mean + std * r * cs);            // the f64 fill holds the f32 values, widened
+    if (i + 1 < n) out[i + 1] = (T)(mean + std * r * sn);
   }
 }
 
@@ -584,7 +588,17 @@ int dm_fill_normal(dm_handle_t h, float *d_ptr, int64_t n, float mean, float std
   if (!d_ptr || n < 0) return fail(h, DM_ERR_INVALID, "dm_fill_normal: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   if (n == 0) return DM_OK;
-  hipLaunchKernelGGL(dm_fill_normal_kernel, dim3(4096), dim3(256), 0, h->stream, d_ptr, n, mean, std, (unsigned long long)seed);
+  hipLaunchKernelGGL(dm_fill_normal_kernel<float>, dim3(4096), dim3(256), 0, h->stream, d_ptr, n, mean, std, (unsigned long long)seed);
+  HIPCHK(h, hipGetLastError());
+  return DM_OK;
+}
+
+int dm_fill_normal_f64(dm_handle_t h, double *d_ptr, int64_t n, float mean, float std, uint64_t seed) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_ptr || n < 0) return fail(h, DM_ERR_INVALID, "dm_fill_normal_f64: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (n == 0) return DM_OK;
+  hipLaunchKernelGGL(dm_fill_normal_kernel<double>, dim3(4096), dim3(256), 0, h->stream, d_ptr, n, mean, std, (unsigned long long)seed);
   HIPCHK(h, hipGetLastError());
   return DM_OK;
 }
@@ -748,6 +762,8 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
     h->ev_pool.push_back({e0, e1});
   }
   *a = h->ev_pool[h->ev_used].first; *b = h->ev_pool[h->ev_used].second;
+  if (h->ev_kind.size() <= h->ev_used) h->ev_kind.resize(h->ev_used + 1);
+  h->ev_kind[h->ev_used] = h->ev_next_kind;
   h->ev_used++;
   return DM_OK;
 }
@@ -755,6 +771,7 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
 template <int E, int KQ, bool SPLIT>
 static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
   HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  if (h->ev_next_kind == 0) snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_kernel<%d, %d, %s>", E, KQ, SPLIT ? "true" : "false");
   hipEvent_t e0, e1;
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
@@ -768,6 +785,7 @@ static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) 
 template <int E, int KQ>
 static int launch_beam_w_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
   HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_w_kernel<E, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_w_kernel<%d, %d>", E, KQ);
   hipEvent_t e0, e1;
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
@@ -945,11 +963,14 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
       p2.user_list = (const int32_t *)((char *)h->d_defer + 16);
       p2.next_user = (unsigned long long *)((char *)h->d_defer + 8);
       p2.defer_count = nullptr; p2.defer_users = nullptr;
+      h->ev_next_kind = 1;
       switch (h->embed) {
-        case 32: return launch_beam_E<32, true>(h, p2, pl2);
-        case 64: return launch_beam_E<64, true>(h, p2, pl2);
-        default: return launch_beam_E<128, true>(h, p2, pl2);
+        case 32: rc = launch_beam_E<32, true>(h, p2, pl2); break;
+        case 64: rc = launch_beam_E<64, true>(h, p2, pl2); break;
+        default: rc = launch_beam_E<128, true>(h, p2, pl2); break;
       }
+      h->ev_next_kind = 0;
+      return rc;
     }
     switch (h->embed) {
       case 32: return launch_beam_E<32, true>(h, p, pl);
@@ -1406,6 +1427,25 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms) {
     tot += ms;
   }
   *launches = (int)h->ev_used; *total_ms = tot;
+  return DM_OK;
+}
+int dm_last_beam_kernel(dm_handle_t h, char *buf, int n) {
+  if (!h || !buf || n <= 0) return DM_ERR_INVALID;
+  snprintf(buf, (size_t)n, "%s", h->last_kernel);
+  return DM_OK;
+}
+int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *total_ms) {
+  if (!h || !launches || !total_ms) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double tot = 0;
+  int n = 0;
+  for (size_t i = 0; i < h->ev_used; i++) {
+    if (h->ev_kind[i] != kind) continue;
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+    tot += ms; n++;
+  }
+  *launches = n; *total_ms = tot;
   return DM_OK;
 }
 // debug (not part of the public header): cumulative per-phase wave cycles, DM_PHASE_TIMERS builds

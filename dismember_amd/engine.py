@@ -403,10 +403,12 @@ class Engine:
         self._chk(N.lib().dm_dr_load_model(self._h, C.byref(m)))
         self.dr_dims = dict(E=E, L=L, K=K, D=D, num_item=num_item, dtype=dt)
 
-    def dr_load_model_synthetic(self, E, L, K, D, num_item, seed, scale=0.05, rerank=True):
-        """Random-init Deep-Retrieval model generated ON THE DEVICE in f32 (N(0, scale) matrices, zero biases —
-        the reference's init, RerankModel.scala:15-16) and loaded without a host copy (bench only)."""
-        fill = lambda n, sd, std: self._fill_new(n, sd, std)
+    def dr_load_model_synthetic(self, E, L, K, D, num_item, seed, scale=0.05, rerank=True, dtype=np.float32):
+        """Random-init Deep-Retrieval model generated ON THE DEVICE (N(0, scale) matrices, zero biases — the reference's
+        init, RerankModel.scala:15-16) and loaded without a host copy (bench only).  dtype float64 (the reference's
+        arithmetic type) holds the same draws as float32, widened."""
+        dt = np.dtype(dtype)
+        fill = lambda n, sd, std: self._fill_new(n, sd, std, dt)
         ptrs = dict(layer_emb=fill((num_item + K * (D - 1)) * E, seed + 1, scale),
                     layer_w=[fill(K * (L + d) * E, seed + 10 + d, scale) for d in range(D)],
                     layer_b=[fill(K, seed + 20 + d, 0.0) for d in range(D)])
@@ -414,15 +416,17 @@ class Engine:
             ptrs.update(rerank_emb=fill(num_item * E, seed + 2, scale), rerank_w=fill(E * L * E, seed + 3, scale),
                         rerank_b=fill(E, seed + 4, 0.0), softmax_w=fill(num_item * E, seed + 5, scale),
                         softmax_b=fill(num_item, seed + 6, 0.0))
-        self.dr_load_model_dev(ptrs, E, L, K, D, num_item, dtype=np.float32)
+        self.dr_load_model_dev(ptrs, E, L, K, D, num_item, dtype=dt)
         self.synchronize()
         for k, v in ptrs.items():
             for q in (v if isinstance(v, list) else [v]):
                 self.dev_free(q)
 
-    def _fill_new(self, n, seed, std):
-        d = self.dev_alloc(int(n) * 4)
-        self._chk(N.lib().dm_fill_normal(self._h, d, int(n), 0.0, float(std), int(seed)))
+    def _fill_new(self, n, seed, std, dtype=np.float32):
+        dt = np.dtype(dtype)
+        d = self.dev_alloc(int(n) * dt.itemsize)
+        fn = N.lib().dm_fill_normal if dt == np.float32 else N.lib().dm_fill_normal_f64
+        self._chk(fn(self._h, d, int(n), 0.0, float(std), int(seed)))
         return d
 
     def dr_load_path_items(self, path_nodes, item_off, items):
@@ -511,6 +515,17 @@ class Engine:
         n, ms = C.c_int(0), C.c_double(0)
         self._chk(N.lib().dm_kernel_timing_get(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def timing_get_kind(self, kind):
+        """launches and summed milliseconds of one kind of launch (0 = search kernels, 1 = deferred-user second pass)"""
+        n, ms = C.c_int(0), C.c_double(0)
+        self._chk(N.lib().dm_kernel_timing_get_kind(self._h, int(kind), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def last_beam_kernel(self):
+        buf = C.create_string_buffer(64)
+        self._chk(N.lib().dm_last_beam_kernel(self._h, buf, 64))
+        return buf.value.decode()
 
     def last_scored_rows(self):
         r = C.c_int64(0)

@@ -356,6 +356,8 @@ int dm_dr_recommend_dev(dm_handle_t h, const int32_t *d_seq_ids, int64_t U, int 
 /* ---- synthetic-data helpers (bench / tests only; nothing in the reference corresponds) ---- */
 /* fill d_ptr[0..n) (float, device) with N(mean, std): counter-based splitmix64 + Box-Muller, reproducible per (seed, index) */
 int dm_fill_normal(dm_handle_t h, float *d_ptr, int64_t n, float mean, float std, uint64_t seed);
+/* the same values (the f32 draws, widened) into a double buffer: an fp64 model with the weights of the f32 one */
+int dm_fill_normal_f64(dm_handle_t h, double *d_ptr, int64_t n, float mean, float std, uint64_t seed);
 /* tree-correlated table for a heap of `depth` levels below the root: row(root) ~ N(0, std),
  * row(c) = rho * row(parent(c)) + sqrt(1 - rho^2) * N(0, std) — a stand-in for a trained index, where
  * a node's embedding summarises its subtree (with iid rows beam search has nothing to follow and
@@ -371,6 +373,11 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
 /* HIP-event pairs around the kernels launched since the last reset (at most the 4096 most recent launches) */
 int dm_kernel_timing_reset(dm_handle_t h);
 int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms);
+/* the same, one kind of launch only: 0 = the search kernels proper, 1 = the second pass over the users the
+ * one-wave-per-SIMD beam kernel hands to the LDS-fed kernel (one launch per search, empty on most inputs) */
+int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *total_ms);
+/* name (with template arguments) of the kernel that ran the last TDM / OTM beam search, as a profiler lists it */
+int dm_last_beam_kernel(dm_handle_t h, char *buf, int n);
 /* scored rows (node, user) pairs of the last beam-search call, for roofline accounting */
 int dm_last_scored_rows(dm_handle_t h, int64_t *rows);
 

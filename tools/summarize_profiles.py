@@ -14,17 +14,22 @@ os.makedirs("profiles", exist_ok=True)
 out = {"tag": tag}
 for f in glob.glob(src + "/trace/*kernel_stats.csv"):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
-    for r in csv.DictReader(open(f)):
-        if "dm_beam_kernel" in r["Name"]:
-            out["kernel_trace"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
-                                   "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
+    best = None
+    for r in csv.DictReader(open(f)):        # the dominant beam kernel: dm_beam_w_kernel<E, KQ> or dm_beam_kernel<E, KQ, SPLIT>
+        if "dm_beam_" in r["Name"] and (best is None or float(r["Percentage"]) > float(best["Percentage"])):
+            best = r
+    if best is not None:
+        r = best
+        out["kernel_trace"] = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                               "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
 pmc = {}
 for d in sorted(glob.glob(src + "/pmc_*")):
     for f in glob.glob(d + "/*counter_collection.csv"):
         acc = collections.defaultdict(float)
         n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if "dm_beam_kernel" in r["Kernel_Name"]:
+            if r["Kernel_Name"].split("(")[0].strip() == out.get("kernel_trace", {}).get("kernel", "dm_beam_kernel").split("(")[0].strip() or \
+               ("kernel_trace" not in out and "dm_beam_" in r["Kernel_Name"]):
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 n[r["Counter_Name"]] += 1
         for k in acc:
