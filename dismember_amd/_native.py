@@ -124,7 +124,7 @@ SIGNATURES = {
     "dm_allreduce_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
     "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
-    "dm_last_beam_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "dm_last_beam_kernel": (C.c_char_p, [C.c_void_p]),
     "dm_kernel_timing_get_kind": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dm_last_scored_rows": (C.c_int, [C.c_void_p, i64p]),
 }

@@ -1429,11 +1429,7 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms) {
   *launches = (int)h->ev_used; *total_ms = tot;
   return DM_OK;
 }
-int dm_last_beam_kernel(dm_handle_t h, char *buf, int n) {
-  if (!h || !buf || n <= 0) return DM_ERR_INVALID;
-  snprintf(buf, (size_t)n, "%s", h->last_kernel);
-  return DM_OK;
-}
+const char *dm_last_beam_kernel(dm_handle_t h) { return h ? h->last_kernel : ""; }
 int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *total_ms) {
   if (!h || !launches || !total_ms) return DM_ERR_INVALID;
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -523,9 +523,7 @@ class Engine:
         return n.value, ms.value
 
     def last_beam_kernel(self):
-        buf = C.create_string_buffer(64)
-        self._chk(N.lib().dm_last_beam_kernel(self._h, buf, 64))
-        return buf.value.decode()
+        return (N.lib().dm_last_beam_kernel(self._h) or b"").decode()
 
     def last_scored_rows(self):
         r = C.c_int64(0)

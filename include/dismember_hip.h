@@ -376,8 +376,9 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms);
 /* the same, one kind of launch only: 0 = the search kernels proper, 1 = the second pass over the users the
  * one-wave-per-SIMD beam kernel hands to the LDS-fed kernel (one launch per search, empty on most inputs) */
 int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *total_ms);
-/* name (with template arguments) of the kernel that ran the last TDM / OTM beam search, as a profiler lists it */
-int dm_last_beam_kernel(dm_handle_t h, char *buf, int n);
+/* name (with template arguments) of the kernel that ran the last TDM / OTM beam search, as a profiler lists it
+ * (owned by the handle, valid until the next search) */
+const char *dm_last_beam_kernel(dm_handle_t h);
 /* scored rows (node, user) pairs of the last beam-search call, for roofline accounting */
 int dm_last_scored_rows(dm_handle_t h, int64_t *rows);
 
