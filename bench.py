@@ -331,7 +331,7 @@ def main():
             pname = "r02_summary.json" if mode != "f32" else "r02_f32_summary.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
             pw = prof["bench_line_under_profiler"]["config"]
-            if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U and prof["kernel_trace"]["kernel"].startswith(kern_name.split("<")[0]):
+            if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U and kern_name in prof["kernel_trace"]["kernel"]:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
                 res["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch, "
                                                      "FETCH x2 gfx950 correction (MI355X_MICROARCH.md)") % pname
