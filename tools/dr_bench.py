@@ -25,12 +25,13 @@ def main():
     ap.add_argument("--embed", type=int, default=128)
     ap.add_argument("--seq-len", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=1)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="model and arithmetic type (f64 = the reference's)")
     a = ap.parse_args()
     E, L, K, D, U = a.embed, a.seq_len, a.K, a.D, a.users
     rng = np.random.default_rng(synth.SEED)
     eng = Engine(0)
     t0 = time.perf_counter()
-    eng.dr_load_model_synthetic(E, L, K, D, a.items, synth.SEED, scale=0.05, rerank=bool(a.rerank))
+    eng.dr_load_model_synthetic(E, L, K, D, a.items, synth.SEED, scale=0.05, rerank=bool(a.rerank), dtype=np.float64 if a.dtype == "f64" else np.float32)
     t_model = time.perf_counter() - t0
     seqs = rng.integers(0, a.items, size=(U, L)).astype(np.int32)
     seqs[rng.random((U, L)) < 0.15] = -1
