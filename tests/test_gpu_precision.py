@@ -6,8 +6,8 @@
     fp32 CPU oracle's own rounding error.  The three error figures are printed and written to gpurun_out/.
   * test_full_size_properties_depth24: the catalogue the metric is quoted on (10 M items, depth 24, E = 128, beam 200: a
     33.5 M x 128 table, past 2^32 bytes AND 2^32 elements) under pytest: TDM and OTM mode, determinism, leaf-set membership,
-    scores == the general forward on rows with codes >= 2^24, and the trace-replay contract against the CPU oracle on a
-    user sample.
+    scores == the general forward on rows with codes >= 2^24, the trace-replay contract against the CPU oracle on a
+    user sample, and one JTM re-assignment step (levels 22 -> 24) against the oracle's aggregateWeights / reBalance.
   * test_otm_trace_exact_replay: the OTM mode's integer logic is exact — CandidateSearcher.buildBeamNodes
     (otm/.../model/CandidateSearcher.scala:109-122) replayed on the scores the GPU produced at every level, both for the
     fp32 beam kernel and for the fp64 pipeline; fp64 scores within 1e-10 / 1e-9 of the oracle's DIN[Double].
@@ -270,4 +270,29 @@ def test_full_size_properties_depth24(oracle):
     oids, _, ocn = otree.recommend_batch(odin, seqs[:256], topk, beam, n_threads=max(1, (os.cpu_count() or 2) - 1))
     same = sum(int(cnt[u] == ocn[u] and np.array_equal(ids[u, :cnt[u]], oids[u, :ocn[u]])) for u in range(256))
     assert same >= 0.95 * 256, same
+    # BASELINE configs[3] at its own size: one JTM re-assignment step on the 10 M-item tree, the step that ends on the leaf level
+    # (levels 22 -> 24: chain nodes with codes >= 2^24 - 1), for a slice of items with 4 training rows each — child weights against the
+    # oracle's aggregateWeights (jtm/.../optim/TreeLearning.scala:137-174), item shards == the full matrix bit for bit, and the
+    # greedy re-balance (:217-265) exact on the device's weights
+    from dismember_amd.jtm import JTM
+    jr = np.random.default_rng(77)
+    nit = 3000
+    pick = np.sort(jr.choice(tree["leaf_ids"].size, nit, replace=False))
+    jitems, jcodes = tree["leaf_ids"][pick], tree["leaf_codes"][pick]
+    jrows = {int(it): seqs[jr.integers(0, U, 4)].reshape(-1) for it in jitems}
+    jt = JTM(eng, jitems, jcodes, depth, jrows, gap=2, seq_len=L)
+    old_level, level = 22, 24
+    item_node = JTM.ancestor_at_level(jt.item_code, old_level)
+    w_gpu = jt.child_weights(item_node, old_level, level)
+    assert w_gpu.shape == (nit, 4) and np.isfinite(w_gpu).all()
+    parts = [jt.weights_range(item_node, old_level, level, a, b) for a, b in ((0, 1000), (1000, 1001), (1001, nit))]
+    assert np.array_equal(np.concatenate(parts, axis=0), w_gpu)
+    w_ref = oracle.jtm_child_weights(otree, odin, jt.items, jt.row_off, jt.row_ids, item_node, L, old_level, level)
+    assert (np.abs(w_gpu - w_ref) <= 4 * 2 * (ATOL + RTOL * np.abs(w_ref / 4))).all()
+    old_node = JTM.ancestor_at_level(jt.item_code, level)
+    for node in np.unique(item_node)[:8]:
+        grp = np.flatnonzero(item_node == node)
+        a = jt.rebalance(w_gpu[grp], old_node[grp], int(node), old_level, level, 1)
+        b = oracle.jtm_rebalance(jt.items[grp], w_gpu[grp], old_node[grp], int(node), old_level, level, 1)
+        assert np.array_equal(a, b)
     eng.close()
