@@ -4,8 +4,8 @@
 Workload: synthetic 10M-item depth-24 binary tree, 128-d embeddings, DIN scorer, beam=200, topk=200, L=10
 (configs/c2_tdm_serve_1m.conf).  One step = one beam search over ONE shard of 131072 users whose
 histories are already resident in HBM; the steps cycle through 8 distinct shards (the 1M-user population).
-N GPUs = N independent user populations (replicated table, no data-path collective; the harness barrier uses
-torch.distributed, the slowest-rank clock dismember_amd.comm).
+N GPUs = N independent user populations (replicated table, no data-path collective; the harness barrier and the
+slowest-rank clock use torch.distributed, the training extra's gradient exchange dismember_amd.comm = RCCL in the library).
 
 Prints ONE JSON line (rank 0).
 """
@@ -175,26 +175,57 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
 
 
 def init_distributed():
-    """The launcher contract (torchrun env): torch.distributed carries only the harness's barrier; the product's own
-    exchange (gradients, result gathers, the slowest-rank clock) runs over dismember_amd.comm (RCCL inside the library)."""
+    """The launcher contract (torchrun env).  torch.distributed carries the HARNESS: the barrier and the slowest-rank clock the
+    bench contract asks for.  What the product exchanges (the training extra's gradients) runs over dismember_amd.comm — RCCL
+    inside the library — created by make_comm() right before it is needed, so that a rendezvous problem there can never cost
+    the headline line."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
-        return None, None, rank, world, local
+        return None, rank, world, local
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if os.environ.get("DM_BENCH_BACKEND", "nccl") == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:                                         # single-GPU smoke test of the N > 1 path (DM_FORCE_DEVICE=0)
+        dist.init_process_group("gloo")
+    return dist, rank, world, local
+
+
+def make_comm(dist, rank, world, local):
+    """The library's communicator for the ranks of this job: rank 0 picks a free port and the harness broadcasts it; RCCL
+    (ncclCommInitRank over the job's GPUs) unless DM_COMM_TRANSPORT says otherwise, the host TCP transport if that fails."""
+    import socket
     from dismember_amd.comm import Comm
-    comm = Comm.from_env(transport=os.environ.get("DM_COMM_TRANSPORT", "rccl"), device_id=int(os.environ.get("DM_FORCE_DEVICE", local)))
-    return dist, comm, rank, world, local
+    dev = int(os.environ.get("DM_FORCE_DEVICE", local))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    err = None
+    for transport in (os.environ.get("DM_COMM_TRANSPORT", "rccl"), "host"):
+        port = [0]
+        if rank == 0:
+            s_ = socket.socket(); s_.bind(("", 0)); port[0] = s_.getsockname()[1]; s_.close()
+        dist.broadcast_object_list(port, src=0)
+        try:
+            c = Comm(world, rank, addr, port[0], transport, dev)
+            ok = 1
+        except Exception as ex:       # noqa: BLE001 — any failure here only costs the training extra
+            c, ok, err = None, 0, repr(ex)
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        if all(oks):
+            return c, transport, None
+        if c is not None:
+            c.close()
+    return None, None, err
 
 
 def main():
     a = parse()
     from dismember_amd import sharding
-    dist, comm, rank, world, local = init_distributed()
+    dist, rank, world, local = init_distributed()
+    comm = None
     torch = None
     if dist is not None:
         import torch
@@ -237,6 +268,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t_ = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
     eng.set_scorer_mode(a.scorer)
     # untimed: one pass per shard records its scored-row count (the roofline's work figure) and builds the scorer's planes
     shard_rows = []
@@ -254,7 +292,7 @@ def main():
         eng.tdm_beam_search_dev(d_seqs[i % NSH], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync(); barrier()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, comm)
+    dt = max_over_ranks(dt)
     n_launch, kernel_ms = eng.timing_get_kind(0)                # the search kernel proper (HIP events on the library's stream)
     n_defer, defer_ms = eng.timing_get_kind(1)                  # second pass over deferred users (one-wave kernel only)
     kern_name = eng.last_beam_kernel()
@@ -282,7 +320,7 @@ def main():
         for _ in range(n_o):
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
-        dto_ = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+        dto_ = max_over_ranks(time.perf_counter() - t0)
         nlo_, kmo_ = eng.timing_get_kind(0)
         kern_o = eng.last_beam_kernel()
         ids_o = np.empty((U, a.topk), np.int32); sc_o = np.empty((U, a.topk), np.float32); cnt_o = np.empty(U, np.int32)
@@ -381,7 +419,7 @@ def main():
         for _ in range(3):
             eng.otm_beam_search_dev(d_os, Uo, L, a.beam, depth, d_oi, d_osc, d_oc)
         sync(); barrier()
-        dto = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+        dto = max_over_ranks(time.perf_counter() - t0)
         t0 = time.perf_counter()
         oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)      # host buffers: PCIe copies of 3.3 KB per user included
         dth = time.perf_counter() - t0
@@ -404,7 +442,7 @@ def main():
         t0 = time.perf_counter()
         wj = jt.child_weights(node10, 10, 12)
         sync(); barrier()
-        dtj = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+        dtj = max_over_ranks(time.perf_counter() - t0)
         jtm = {"workload": "JTM re-assignment scoring, one gap-2 step (levels 10 -> 12): %d items x 4 training rows x 6 chain nodes "
                            "= %d DIN rows per worker; pairs expanded, scored and summed (reference-order fp32) on the device, host buffers in and out" % (ni_j, ni_j * 4 * 6),
                "items_per_s": world * ni_j / dtj, "din_rows_per_s": world * ni_j * 24 / dtj, "ms": dtj * 1e3,
@@ -435,7 +473,7 @@ def main():
         for _ in range(nst):
             eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
         sync(); barrier()
-        dt2 = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+        dt2 = max_over_ranks(time.perf_counter() - t0)
         nl2, kms2 = eng.timing_get_kind(0)
         rows2 = eng.last_scored_rows()
         small = {"workload": "TDM beam-search serving, synthetic %d-item depth-%d tree, %d-d, beam=%d, topk=%d (BASELINE.json configs[1])"
@@ -460,7 +498,12 @@ def main():
                 same = sum(int(cnt2[u] == ocnt[u] and np.array_equal(ids2[u, :cnt2[u]], oids[u, :ocnt[u]])) for u in range(len(ocnt)))
                 base["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
                 small["cpu_baseline"] = base
-        if a.train:
+        comm_note = None
+        if a.train and dist is not None:
+            comm, comm_transport, comm_err = make_comm(dist, rank, world, local)
+            if comm is None:
+                comm_note = "training extra skipped: no communicator (%s)" % comm_err
+        if a.train and (dist is None or comm is not None):
             from dismember_amd.trainer import TDMTrainer
             neg = np.array(a.params["layer_negative_counts_list"], np.int32)            # model.layer_negative_counts
             per = int(sum(1 + neg[l] for l in range(1, depth2 + 1)))
@@ -477,12 +520,15 @@ def main():
             for _ in range(nts):
                 tloss = tr.step(tseq, ttgt)
             sync(); barrier()
-            dtt = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+            dtt = max_over_ranks(time.perf_counter() - t0)
             nparam = ni2 * E + 3 * E * E + 2 * E + 1
             train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives drawn on the device), "
                                  "DIN fwd+bwd, gradient exchange (dm_train_sync_gradients: RCCL inside the library), dense Adam over %d parameters" % (Tt, Tt * per, nparam),
                      "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
-                     "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world}
+                     "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world,
+                     "gradient_exchange": ("dm_train_sync_gradients over dm_comm (%s)" % comm_transport) if comm is not None else "single worker"}
+        elif comm_note:
+            train = {"skipped": comm_note}
     # ---- extra: Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=1000, beam=50, 10M items.  The record is the fp64
     #      run (the reference's arithmetic type, deep-retrieval/.../model/LayerModel.scala); the f32 model with the split-fp16
     #      history GEMM is timed beside it on the same inputs ----
@@ -512,7 +558,7 @@ def main():
             for _ in range(nsd):
                 eng.dr_beam_search_dev(q_seq, Ud, beam_d, q_paths, q_probs, q_cnt)
             sync(); barrier()
-            dtb = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+            dtb = max_over_ranks(time.perf_counter() - t0)
             _, kms_b = eng.timing_get()
             paths_h = np.empty((Ud, beam_d, Dd), np.int32)
             eng.d2h(paths_h, q_paths)
@@ -522,7 +568,7 @@ def main():
             for _ in range(nsd):
                 eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
             sync(); barrier()
-            dtr = sharding.max_over_ranks(time.perf_counter() - t0, comm)
+            dtr = max_over_ranks(time.perf_counter() - t0)
             runs[tag] = {"beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
                          "beam_search_kernel_ms_per_step": kms_b / nsd, "recommend_users_per_s": world * Ud * nsd / dtr,
                          "paths": paths_h}
