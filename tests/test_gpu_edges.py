@@ -278,3 +278,34 @@ def test_long_history_forward_follows_training(oracle, fixture_w32):
         ref = oracle.Din(w, 16, L, 8191).forward(codes, seqs, pad)
         assert (np.abs(got - ref) <= 1e-5 + 1e-4 * np.abs(ref)).all(), L
     eng.close()
+
+
+@pytest.mark.parametrize("E", [16, 32, 128])
+def test_prune_order_with_mass_ties_and_signed_zeros(oracle, E):
+    """The prune is a STABLE descending sort by Float.compareTo (Recommender.scala:74-87): equal scores keep frontier order,
+    -0.0 sorts below +0.0.  Tables built so that whole levels tie exactly: (a) every embedding row identical -> every score of a
+    level identical; (b) rows drawn from FOUR distinct vectors -> crowded ties; (c) second-layer weights and bias zero ->
+    every score is +0.0 or (negative-weight variant) -0.0.  The trace-replay contract then checks the order bit for bit — this
+    exercises the register sort's packed (score key, position) keys of the one-wave-per-SIMD kernel and the LDS-fed kernel alike."""
+    from helpers import random_din_weights, random_histories, synthetic_tree
+    from test_gpu_parity import make_engine, replay_and_check
+    rng = np.random.default_rng(900 + E)
+    depth, n_items = 10, 900
+    NI = (1 << (depth + 1)) - 1
+    t = synthetic_tree(rng, depth, n_items)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    seqs = random_histories(rng, t["leaf_ids"], 6, 10)
+    base = random_din_weights(rng, E, NI)
+    emb = base[:NI * E].reshape(NI, E)
+    variants = {}
+    a = base.copy(); a[:NI * E].reshape(NI, E)[:] = emb[5]; variants["all_rows_equal"] = a
+    b = base.copy(); b[:NI * E].reshape(NI, E)[:] = emb[rng.integers(0, 4, NI)]; variants["four_row_values"] = b
+    tail0 = NI * E + E * E + 2 * E * E + E           # [emb ; att.W ; l1.W (E x 2E) ; l1.b] then l2.W [E], l2.b [1]
+    c = base.copy(); c[tail0:tail0 + E + 1] = 0.0; variants["zero_output_layer"] = c
+    d = base.copy(); d[tail0:tail0 + E] = -0.0; d[tail0 + E] = -0.0; variants["negative_zero_output_layer"] = d
+    for name, w in variants.items():
+        eng = make_engine(t, w, E)
+        odin = oracle.Din(w, E, 10, NI)
+        for beam, topk in ((200, 50), (37, 37), (256, 300)):
+            replay_and_check(otree, odin, eng, seqs, beam, topk)
+        eng.close()
