@@ -92,6 +92,8 @@ struct dm_ctx {
   void *d_req = nullptr;
   size_t req_bytes = 0;
   unsigned long long h_rows = 0;
+  char *h_stage = nullptr;     // pinned staging block for small host-buffer requests (one upload, one download per call)
+  size_t stage_bytes = 0;
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -312,6 +314,7 @@ int dm_destroy(dm_handle_t h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
   dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1111,7 +1114,18 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
     d_ids = (int32_t *)base; base += b_out;
     d_scores = (float *)base; base += b_out;
     d_counts = (int32_t *)base; base += b_cnt;
-    if (hipMemcpyAsync(d_seq, seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+    // small requests (the reference's one-user-per-call serving loop): the request goes up and the three result arrays come down
+    // through ONE pinned staging block — a pageable copy costs 10-15 us each, and a single-user search is 60 us of kernel
+    const size_t down = 2 * b_out + b_cnt;
+    const bool staged = !coff && !tn && b_seq + down <= (256u << 10);
+    if (staged && h->stage_bytes < b_seq + down) {
+      if (h->h_stage) (void)hipHostFree(h->h_stage);
+      h->h_stage = nullptr; h->stage_bytes = 0;
+      if (hipHostMalloc((void **)&h->h_stage, 256u << 10, hipHostMallocDefault) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "hipHostMalloc failed"); break; }
+      h->stage_bytes = 256u << 10;
+    }
+    if (staged) memcpy(h->h_stage, seq, (size_t)U * L * 4);
+    if (hipMemcpyAsync(d_seq, staged ? (const void *)h->h_stage : (const void *)seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
     if (coff) {
       d_coff = (int64_t *)base; base += b_coff;
       d_cids = (int32_t *)base; base += b_cids;
@@ -1128,19 +1142,27 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
     }
     rc = tdm_search_dev(h, d_seq, U, L, opts, mb, d_coff, d_cids, d_ids, d_scores, d_counts, tn ? max_levels : 0, d_tc, d_ts, d_tn);
     if (rc != DM_OK) break;
-    hipError_t e = hipMemcpyAsync(out_ids, d_ids, nout * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, nout * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipSuccess;
+    if (staged) {
+      e = hipMemcpyAsync(h->h_stage + b_seq, d_ids, down, hipMemcpyDeviceToHost, h->stream);       // ids | scores | counts are one block of the arena
+    } else {
+      e = hipMemcpyAsync(out_ids, d_ids, nout * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_scores, nout * 4, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream);
+    }
     if (e == hipSuccess && tn) {
       const size_t nt = (size_t)U * max_levels;
       e = hipMemcpyAsync(tc, d_tc, nt * cap * 4, hipMemcpyDeviceToHost, h->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts, nt * cap * 4, hipMemcpyDeviceToHost, h->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(tn, d_tn, nt * 4, hipMemcpyDeviceToHost, h->stream);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h->h_rows, h->d_rows, 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { rc = fail(h, DM_ERR_HIP, std::string("tdm beam search: ") + hipGetErrorString(e)); break; }
-    h->last_rows = (int64_t)h->h_rows;
+    if (staged) {
+      memcpy(out_ids, h->h_stage + b_seq, nout * 4);
+      memcpy(out_scores, h->h_stage + b_seq + b_out, nout * 4);
+      memcpy(out_counts, h->h_stage + b_seq + 2 * b_out, (size_t)U * 4);
+    }
   } while (0);
   dm_free_ptr(d_tc); dm_free_ptr(d_tn); dm_free_ptr(d_ts);      // trace buffers (parity instrumentation) are per call
   return rc;
