@@ -21,10 +21,15 @@ def lower_log2(n):
 
 
 class OTMTrainer:
-    def __init__(self, engine, leaf_level, beam, seq_len=10, lr=1e-3):
+    def __init__(self, engine, leaf_level, beam, seq_len=10, lr=1e-3, comm=None):
+        """comm: dismember_amd.comm.Comm — one worker per GPU, users sharded over the workers; every level's gradients go
+        through dm_train_sync_gradients (syncGradients, otm/.../optim/LocalOptimizer.scala:217-233) before the shared Adam step."""
         self.e, self.leaf_level, self.beam, self.L = engine, int(leaf_level), int(beam), int(seq_len)
         self.start_level = lower_log2(beam)
+        self.comm = comm
         engine.train_init(lr=lr)
+        if comm is not None:
+            engine.attach_comm(comm)
 
     # ---- model evaluations
     def _forward(self, nodes, row_seqs):
@@ -96,6 +101,12 @@ class OTMTrainer:
                     codes.append(n); rows.append(seqs[u]); labels.append(tl[u].get(n, 0.0))
             rows = _i32(rows).reshape(-1, self.L)
             pad = np.flatnonzero(rows.reshape(-1) == -1).astype(np.int32)
-            losses.append(self.e.train_forward_backward(_i32(codes), rows, pad, np.asarray(labels, np.float32)))
-            self.e.adam_step(1.0)
+            loss = self.e.train_forward_backward(_i32(codes), rows, pad, np.asarray(labels, np.float32))
+            world = 1
+            if self.comm is not None:
+                world = self.comm.world
+                self.e.train_sync_gradients()
+                loss = self.comm.allreduce(float(loss)) / world
+            losses.append(loss)
+            self.e.adam_step(1.0 / world)
         return losses

@@ -107,3 +107,38 @@ def test_sync_without_communicator_fails():
         eng.train_sync_gradients()
     assert e.value.code == -3
     eng.close()
+
+
+def _otm_worker(rank, world, port, q):
+    from dismember_amd import Engine
+    from dismember_amd.comm import Comm
+    from dismember_amd.otm_train import OTMTrainer
+    w = np.load(os.path.join(GOLDEN, "din_f32.npy"))
+    eng = Engine(0)
+    eng.load_weights_din(w, 16, 8191)
+    comm = Comm(world, rank, "127.0.0.1", port, transport="host")
+    tr = OTMTrainer(eng, leaf_level=12, beam=20, lr=1e-3, comm=comm)
+    rng = np.random.default_rng(40 + rank)                     # every worker: its own users (node-id histories, leaf targets)
+    codes = rng.integers(4095, 8191, (6, 10)).astype(np.int32)
+    codes[rng.random((6, 10)) < 0.2] = -1
+    targets = [rng.integers(4095, 8191, int(rng.integers(1, 4))).tolist() for _ in range(6)]
+    losses = tr.train_batch(codes, targets)
+    q.put((rank, losses, eng.train_download("weights")))
+    comm.barrier()
+    eng.close(); comm.close()
+
+
+def test_otm_trainer_replicas_stay_identical():
+    """BASELINE configs[2]: OTM training with users sharded over workers — one gradient exchange and one Adam step per tree level
+    (otm/.../optim/LocalOptimizer.scala:73-80, 217-233); replicas must hold the same bits after a whole iteration."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_otm_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert out[0][1] == out[1][1] and len(out[0][1]) == 12 - 4 and all(np.isfinite(out[0][1]))       # the averaged per-level losses
+    assert np.array_equal(out[0][2], out[1][2])
+    assert not np.array_equal(out[0][2], np.load(os.path.join(GOLDEN, "din_f32.npy")))
