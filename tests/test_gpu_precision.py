@@ -7,7 +7,8 @@
   * test_full_size_properties_depth24: the catalogue the metric is quoted on (10 M items, depth 24, E = 128, beam 200: a
     33.5 M x 128 table, past 2^32 bytes AND 2^32 elements) under pytest: TDM and OTM mode, determinism, leaf-set membership,
     scores == the general forward on rows with codes >= 2^24, the trace-replay contract against the CPU oracle on a
-    user sample, and one JTM re-assignment step (levels 22 -> 24) against the oracle's aggregateWeights / reBalance.
+    user sample, one OTM training iteration (20 levels, dense Adam over 4.29 G parameters) and one JTM re-assignment step
+    (levels 22 -> 24) against the oracle's aggregateWeights / reBalance.
   * test_otm_trace_exact_replay: the OTM mode's integer logic is exact — CandidateSearcher.buildBeamNodes
     (otm/.../model/CandidateSearcher.scala:109-122) replayed on the scores the GPU produced at every level, both for the
     fp32 beam kernel and for the fp64 pipeline; fp64 scores within 1e-10 / 1e-9 of the oracle's DIN[Double].
@@ -256,6 +257,20 @@ def test_full_size_properties_depth24(oracle):
         pad = np.flatnonzero(np.tile(ocodes[u] < 0, 2 * beam)).astype(np.int32)
         ref = eng.din_forward(oid[u], np.tile(ocodes[u], (2 * beam, 1)), pad, L=L)
         assert (np.abs(osc[u] - ref) <= ATOL + RTOL * np.abs(ref)).all()
+    # BASELINE configs[2] at its own size: one OTM training iteration on the complete depth-24 tree (4.29 G parameters; weights,
+    # gradient and the two Adam vectors are 69 GB on the device) — pseudo targets, beam nodes and one forward/backward + dense Adam
+    # per level (otm/.../optim/LocalOptimizer.scala:55-109): finite per-level losses, and the same batch trained again scores lower
+    from dismember_amd.otm_train import OTMTrainer
+    otr = OTMTrainer(eng, depth, 20, seq_len=L, lr=1e-3)
+    trng = np.random.default_rng(12)
+    first = (1 << depth) - 1
+    tcodes = np.where(seqs[:6] > 0, lut[np.clip(seqs[:6], 0, lut.size - 1)], -1).astype(np.int32)
+    ttargets = [(first + trng.integers(0, 1 << depth, size=2)).tolist() for _ in range(6)]
+    l1 = otr.train_batch(tcodes, ttargets)
+    l2 = otr.train_batch(tcodes, ttargets)
+    assert len(l1) == depth - 4 and np.isfinite(l1).all() and np.isfinite(l2).all()
+    assert sum(l2) < sum(l1)
+    eng.load_weights_din_synthetic(E, NI, synth.SEED, tree_depth=depth, rho=0.95)          # back to the untrained table for the replay below
     # trace-replay contract against the CPU oracle on a user sample (needs a host copy of the 17.2 GB table)
     table_bytes = (NI * E + 3 * E * E + 2 * E + 1) * 4
     if _host_mem_available() < 2 * table_bytes + (8 << 30):
