@@ -9,7 +9,7 @@ U = 16384
 E, L, K, D, beam = 128, 10, 1000, 3, 50
 rng = np.random.default_rng(synth.SEED)
 eng = Engine(0)
-eng.dr_load_model_synthetic(E, L, K, D, 1_000_000, synth.SEED, rerank=False)
+eng.dr_load_model_synthetic(E, L, K, D, 1_000_000, synth.SEED, rerank=False, dtype=np.float64 if (len(sys.argv) > 2 and sys.argv[2] == 'f64') else np.float32)
 seqs = rng.integers(0, 1_000_000, size=(U, L)).astype(np.int32)
 d_seq = eng.dev_alloc(U * L * 4); eng.h2d(d_seq, seqs)
 d_paths = eng.dev_alloc(U * beam * D * 4); d_probs = eng.dev_alloc(U * beam * 8); d_cnt = eng.dev_alloc(U * 4)
