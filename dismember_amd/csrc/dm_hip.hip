@@ -21,6 +21,7 @@
 
 #include "beam_kernel.hip.inc"
 #include "beam_kernel_w.hip.inc"
+#include "beam_kernel_f64.hip.inc"
 #include "rows_kernel.hip.inc"
 #include "train_kernel.hip.inc"
 #include "dr_kernel.hip.inc"
@@ -67,6 +68,10 @@ struct dm_ctx {
   unsigned *d_maxabs = nullptr;
   int sh_e = 0, sh_w = 0;
   void *d_att_wT_t = nullptr, *d_l1T_t = nullptr;  // transposes in the loaded dtype (general forward)
+  // fp64 beam kernel (beam_kernel_f64.hip.inc): A / B fragments of att.W, W1a, W1b; per-team K / G fragment scratch
+  void *d_frag64 = nullptr, *d_scratch64 = nullptr;
+  bool frag64_dirty = true;
+  size_t scratch64_bytes = 0;
   // training state (dm_train_init)
   bool train_ready = false;
   dm_adam_opts adam{};
@@ -300,6 +305,7 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
   dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
+  dm_free_ptr(h->d_frag64); h->d_frag64 = nullptr; h->frag64_dirty = true;
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
@@ -315,7 +321,7 @@ int dm_destroy(dm_handle_t h) {
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
-  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer);
+  dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer); dm_free_ptr(h->d_scratch64);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
