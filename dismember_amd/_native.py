@@ -73,7 +73,8 @@ SIGNATURES = {
     "dm_train_init": (C.c_int, [C.c_void_p, C.POINTER(AdamOpts)]),
     "dm_train_forward_backward": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int64, f32p, C.c_int64, C.c_int, f32p]),
     "dm_adam_step": (C.c_int, [C.c_void_p, C.c_float]),
-    "dm_train_download": (C.c_int, [C.c_void_p, C.c_int, f32p, C.c_int64]),
+    "dm_train_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dm_train_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "dm_train_dense_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),
     "dm_train_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
     "dm_train_add_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "dm_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dm_comm_all_gather_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "dm_train_sync_gradients": (C.c_int, [C.c_void_p]),
+    "dm_train_sync_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "dm_allreduce_grads": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dm_kernel_timing_reset": (C.c_int, [C.c_void_p]),
     "dm_kernel_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),

@@ -76,7 +76,11 @@ struct dm_ctx {
   bool train_ready = false;
   dm_adam_opts adam{};
   int adam_t = 0;
-  float *d_grad = nullptr, *d_adam_s = nullptr, *d_adam_r = nullptr, *d_loss = nullptr;
+  void *d_grad = nullptr, *d_adam_s = nullptr, *d_adam_r = nullptr, *d_loss = nullptr;   // in the loaded dtype
+  void *d_tr64 = nullptr;        // f64 model: A fragments of att.W, W1a, W1b and of their transposes for the training kernels
+  void *d_tail32 = nullptr;      // f64 model: f32 copy of the small matrices (source of the f32 mirror's fragments)
+  bool f32_mirror_dirty = false; // f64 model whose weights moved: the f32 copies the throughput beam kernels read are stale
+  double last_loss = 0.0;
   f32x4 *d_attTA = nullptr, *d_w1aTA = nullptr, *d_w1bTA = nullptr;
   unsigned *d_touch_bits = nullptr;
   int32_t *d_touch_list = nullptr;
@@ -306,6 +310,7 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
   dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
   dm_free_ptr(h->d_frag64); h->d_frag64 = nullptr; h->frag64_dirty = true;
+  dm_free_ptr(h->d_tr64); h->d_tr64 = nullptr; dm_free_ptr(h->d_tail32); h->d_tail32 = nullptr; h->f32_mirror_dirty = false;
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
@@ -920,7 +925,14 @@ static int ensure_split(dm_ctx *h) {
   return DM_OK;
 }
 
+static int ensure_f32_mirror(dm_ctx *h);
 static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
+  {   // f64 model trained since the f32 copies were made: refresh them (and the scorer parameters fill_common took from them)
+    const bool was = h->f32_mirror_dirty;
+    int rc_ = ensure_f32_mirror(h);
+    if (rc_ != DM_OK) return rc_;
+    if (was) p.b2 = h->b2;
+  }
   // the brute-force recall oracle (mode 2) always scores with the fp32-input MFMA
   if (h->scorer_mode == DM_SCORER_SPLIT_F16 && h->embed % 32 != 0)
     return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size of 32, 64 or 128");

@@ -254,7 +254,19 @@ class Engine:
         loss = C.c_float(0)
         self._chk(N.lib().dm_train_forward_backward(self._h, _p(codes, N.i32p), _p(seqs, N.i32p), _p(pad, N.i32p), pad.size,
                                                     _p(lab, N.f32p), B, L, C.byref(loss)))
-        return loss.value
+        return self.train_last_loss() if self.dtype == np.float64 else loss.value
+
+    def train_last_loss(self):
+        """The loss of the last forward/backward in the model's precision (dm_train_last_loss)."""
+        v = C.c_double(0)
+        self._chk(N.lib().dm_train_last_loss(self._h, C.byref(v)))
+        return v.value
+
+    def train_sync_stats(self):
+        o = (C.c_uint64 * 8)()
+        self._chk(N.lib().dm_train_sync_stats(self._h, o))
+        return {"nranks": int(o[0]), "transport": "rccl" if o[1] == 1 else "host", "rows_mine": int(o[2]), "rows_total": int(o[3]),
+                "bytes_sent": int(o[4]), "bytes_recv": int(o[5]), "host_syncs": int(o[6])}
 
     def set_node_probs(self, codes, probs):
         """Node.probality per tree node (needed by sample_with_probability)."""
@@ -355,8 +367,8 @@ class Engine:
 
     def train_download(self, what="weights"):
         n = self.num_index * self.E + 3 * self.E * self.E + 2 * self.E + 1
-        out = np.empty(n, np.float32)
-        self._chk(N.lib().dm_train_download(self._h, {"weights": 0, "grad": 1, "s": 2, "r": 3}[what], _p(out, N.f32p), n))
+        out = np.empty(n, self.dtype)          # the loaded dtype: fp64 models train in fp64
+        self._chk(N.lib().dm_train_download(self._h, {"weights": 0, "grad": 1, "s": 2, "r": 3}[what], out.ctypes.data_as(C.c_void_p), n))
         return out
 
     # ---- Deep-Retrieval (row A13)

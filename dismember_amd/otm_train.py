@@ -4,7 +4,8 @@ Mirror of otm/src/main/scala/com/mass/otm/optim/LocalOptimizer.scala:55-140 with
 OTMTree.optimalPseudoTargets / beamSearchNodes (otm/.../tree/OTMTree.scala:27-91,104-212) and
 MiniBatch.batchTransform (otm/.../dataset/MiniBatch.scala:17-40).  Every model evaluation runs on the device
 (general-rows forward, beam kernel in OTM mode with its per-level trace, training kernels); the label bookkeeping
-is small host code.  The reference runs this path in fp64; the device path is fp32 (tolerances in DESIGN.md).
+is small host code.  The arithmetic follows the loaded model: an f64 model (the reference's DIN[Double]) is searched by
+the fp64 beam kernel and trained by the fp64 kernels with fp64 Adam state; an f32 model runs the throughput kernels.
 
 computeTargets' mirrored prediction offsets (a reference quirk, OTMTree.scala:115-128) are reproduced.
 """
@@ -43,11 +44,14 @@ class OTMTrainer:
         U = seqs.shape[0]
         levels = self.leaf_level - self.start_level
         cap = max(32, ((2 * self.beam + 15) // 16) * 16)
-        ids = np.empty((U, 2 * self.beam), np.int32); sc = np.empty((U, 2 * self.beam), np.float32); cnt = np.empty(U, np.int32)
-        tc = np.zeros((U, levels, cap), np.int32); ts = np.zeros((U, levels, cap), np.float32); tn = np.zeros((U, levels), np.int32)
-        self.e._chk(N.lib().dm_otm_beam_search_trace(self.e._h, _p(seqs, N.i32p), U, self.L, self.beam, self.leaf_level,
-                                                     _p(ids, N.i32p), _p(sc, N.f32p), _p(cnt, N.i32p), levels,
-                                                     _p(tc, N.i32p), _p(ts, N.f32p), _p(tn, N.i32p)))
+        if self.e.dtype == np.float64 and self.e.scorer_mode()["mode"] == "f64":
+            _, _, _, tc, ts, tn = self.e.otm_beam_search_f64(seqs, self.beam, self.leaf_level, trace_levels=levels)
+        else:
+            ids = np.empty((U, 2 * self.beam), np.int32); sc = np.empty((U, 2 * self.beam), np.float32); cnt = np.empty(U, np.int32)
+            tc = np.zeros((U, levels, cap), np.int32); ts = np.zeros((U, levels, cap), np.float32); tn = np.zeros((U, levels), np.int32)
+            self.e._chk(N.lib().dm_otm_beam_search_trace(self.e._h, _p(seqs, N.i32p), U, self.L, self.beam, self.leaf_level,
+                                                         _p(ids, N.i32p), _p(sc, N.f32p), _p(cnt, N.i32p), levels,
+                                                         _p(tc, N.i32p), _p(ts, N.f32p), _p(tn, N.i32p)))
         return [[list(zip(tc[u, lv, :tn[u, lv]].tolist(), ts[u, lv, :tn[u, lv]].tolist())) for u in range(U)]
                 for lv in range(levels)]
 

@@ -205,21 +205,26 @@ int dm_otm_rebalance(dm_handle_t h, const double *weights, const int32_t *old_no
  *   dm_adam_step(1/n_workers)   == Adam.optimize (scalann/.../optim/Adam.scala:19-73), DENSE over the whole
  *                                  compact vector (untouched embedding rows still move through s, r), then
  *                                  the gradient is zeroed (zeroGradParameters).
- * f32 weights only. */
+ * The step runs in the LOADED dtype: f32 models (TDM / JTM, T/model/DIN.scala) train in fp32, f64 models (the reference's OTM,
+ * DIN[Double]: O/model/DIN.scala:12-39, O/optim/LocalOptimizer.scala:55-140,217-233) in fp64 on v_mfma_f64_16x16x4_f64 with an
+ * fp64 gradient and fp64 Adam state.  Labels are float in both (0 / 1, or pseudo targets clipped to [0, 1]); `loss` is the
+ * value rounded to float, dm_train_last_loss returns it in the model's precision.  Vectors that cross the boundary
+ * (dm_train_download, dm_train_dense_block, dm_train_export_rows, dm_train_add_rows) hold elements of the loaded dtype. */
 typedef struct { double lr, lr_decay, beta1, beta2, eps; } dm_adam_opts;   /* reference defaults: 1e-3, 0, 0.9, 0.999, 1e-8 */
 int dm_train_init(dm_handle_t h, const dm_adam_opts *opts);
 int dm_train_forward_backward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
                               int64_t n_pad, const float *labels, int64_t B, int L, float *loss);
 int dm_adam_step(dm_handle_t h, float grad_scale);
+int dm_train_last_loss(dm_handle_t h, double *loss);
 /* what: 0 weights, 1 gradient, 2 Adam s, 3 Adam r — host copy of the full compact-layout vector (tests, checkpoints) */
-int dm_train_download(dm_handle_t h, int what, float *out, int64_t n);
+int dm_train_download(dm_handle_t h, int what, void *out, int64_t n);
 /* Gradient exchange for N workers on N GPUs: the dense block [att.W ; l1.W ; l1.b ; l2.W ; l2.b]
  * is all-reduced in place through the returned device pointer (RCCL); embedding gradients are row-sparse:
  * export this worker's unique touched rows (index + gradient row, device buffers), all-gather them, add the
  * other workers' rows.  Replicas stay bit-identical because every rank applies the same sums in the same order. */
-int dm_train_dense_block(dm_handle_t h, float **d_ptr, int64_t *n);
-int dm_train_export_rows(dm_handle_t h, int32_t *d_rows, float *d_grads, int64_t cap, int64_t *n);   /* NULL buffers: size query */
-int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const float *d_grads, int64_t n);
+int dm_train_dense_block(dm_handle_t h, void **d_ptr, int64_t *n);
+int dm_train_export_rows(dm_handle_t h, int32_t *d_rows, void *d_grads, int64_t cap, int64_t *n);   /* NULL buffers: size query */
+int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const void *d_grads, int64_t n);
 
 /* ---- multi-GPU: communicators and the gradient exchange ------------------------------------------
  * The reference's data parallelism is N worker threads in one JVM whose gradient buffers are averaged in place
@@ -232,7 +237,12 @@ int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const float *d_grads
  *                 (RCCL refuses two ranks per device) and CPU-only processes for the host-buffer collectives.
  * dm_train_sync_gradients(h) == syncGradients minus the division (dm_adam_step(1/N) folds it in): all-reduce(sum) of the
  * dense block + all-gather of (touched row, gradient row) lists, each touched row rebuilt as 0 + g_0 + g_1 + ... in rank
- * order, so every replica ends with bit-identical gradients.  Collective: every rank must call it. */
+ * order, so every replica ends with bit-identical gradients (the RCCL dense sum is identical on all ranks but in RCCL's
+ * reduction order, not rank order; the HOST transport sums in rank order).  RCCL transport: one ncclAllGather of 16-byte
+ * {count, ok} records + ONE host read-back, then one ncclAllReduce and one ncclAllGather of max-padded row blocks.
+ * Collective: every rank must call it; a rank whose touched-row list overflowed makes EVERY rank return DM_ERR_STATE.
+ * dm_train_sync_stats: what the last exchange of this process moved — out[0..7] = nranks, transport, touched rows of this
+ * rank, touched rows of all ranks, bytes sent, bytes received, host synchronisations, 0. */
 typedef struct dm_comm *dm_comm_t;
 enum { DM_COMM_HOST = 0, DM_COMM_RCCL = 1 };
 #define DM_COMM_ID_BYTES 128
@@ -253,6 +263,7 @@ int dm_comm_all_gather_v(dm_comm_t c, const void *send, size_t bytes, void *recv
 int dm_comm_attach(dm_handle_t h, dm_comm_t c);                       /* the handle does not own c; NULL detaches */
 int dm_comm_all_gather_dev(dm_handle_t h, const void *d_send, size_t bytes, void *d_recv, size_t recv_cap, uint64_t *sizes);
 int dm_train_sync_gradients(dm_handle_t h);
+int dm_train_sync_stats(dm_handle_t h, uint64_t *out8);
 /* SURVEY.md §8b `dm_allreduce_grads(h[], n_gpu)`: the same exchange for ALL ranks of a dm_comm_create_all clique from one
  * thread (hs[i] must carry rank i); n == 1 is dm_train_sync_gradients. */
 int dm_allreduce_grads(dm_handle_t *hs, int n);

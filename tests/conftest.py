@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung kernel must fail ONE test, not hold the GPU box until the driver's limit: every GPU test gets a wall-clock bound
+    (pytest-timeout is in the image; the full-size depth-24 cases get more)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if "gpu" in it.keywords and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(1500 if "full_size" in it.name else 420))
+
+
 @pytest.fixture(scope="session")
 def fixture_tree():
     return dict(np.load(os.path.join(GOLDEN, "tdm_tree.npz")))

@@ -23,6 +23,14 @@ struct JNINativeInterface_ {
   jobject (*GetObjectArrayElement)(JNIEnv *, jobjectArray, jsize);
   jdouble *(*GetDoubleArrayElements)(JNIEnv *, jdoubleArray, jboolean *);
   void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
+  jfloat *(*GetFloatArrayElements)(JNIEnv *, jfloatArray, jboolean *);
+  void (*ReleaseFloatArrayElements)(JNIEnv *, jfloatArray, jfloat *, jint);
+  jint *(*GetIntArrayElements)(JNIEnv *, jintArray, jboolean *);
+  void (*ReleaseIntArrayElements)(JNIEnv *, jintArray, jint *, jint);
+  jlong *(*GetLongArrayElements)(JNIEnv *, jlongArray, jboolean *);
+  void (*ReleaseLongArrayElements)(JNIEnv *, jlongArray, jlong *, jint);
+  jbyte *(*GetByteArrayElements)(JNIEnv *, jbyteArray, jboolean *);
+  void (*ReleaseByteArrayElements)(JNIEnv *, jbyteArray, jbyte *, jint);
   void *(*GetPrimitiveArrayCritical)(JNIEnv *, jarray, jboolean *);
   void (*ReleasePrimitiveArrayCritical)(JNIEnv *, jarray, void *, jint);
 };

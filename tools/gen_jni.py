@@ -9,10 +9,15 @@ dismember_amd/_native.SIGNATURES.  The reference reaches native code the same wa
 project/Dependencies.scala:27-29); nothing here is compiled in the build image (no JVM), the shim is compile-guarded on
 JAVA_HOME by jni/Makefile.
 
-Mapping: handle / communicator / device pointer -> jlong; `const T *` host arrays -> primitive arrays pinned with
-GetPrimitiveArrayCritical (released with JNI_ABORT when const, copied back otherwise; null allowed); `T *out` scalars ->
-arrays of length 1; option structs -> their fields as scalars; host `void *` buffers -> one method per element type;
-a non-zero status becomes the exception the Scala code would have thrown (raise()).
+Mapping: handle / communicator / device pointer -> jlong; `const T *` host arrays -> primitive arrays (released with
+JNI_ABORT when const, copied back otherwise; null allowed); `T *out` scalars -> arrays of length 1; option structs -> their
+fields as scalars; host `void *` buffers -> one method per element type; a non-zero status becomes the exception the Scala
+code would have thrown (raise(); communicator calls report dm_comm_last_error).
+
+Array access: the JNI spec forbids blocking (on other threads, the network, or a long-running device) inside a
+Get/ReleasePrimitiveArrayCritical region — a thread parked in a collective while another is stalled by the GC locker
+deadlocks the JVM.  Only the entry points listed in CRITICAL_OK (pure host logic and plain copies) pin their arrays that
+way; every other call goes through Get<Type>ArrayElements / Release<Type>ArrayElements, which may copy.
 """
 import os
 import re
@@ -38,6 +43,7 @@ ARRAY = {"int32_t": ("jintArray", "jint", "Array[Int]"), "int": ("jintArray", "j
 VOID_HOST = {
     "dm_load_weights_din": {"compact": [("F32", "float"), ("F64", "double")]},     # dtype is fixed by the variant (FIXED below)
     "dm_din_forward": {"logits": [("F32", "float"), ("F64", "double")]},
+    "dm_train_download": {"out": [("F32", "float"), ("F64", "double")]},               # the loaded dtype
     "dm_comm_unique_id": {"id128": [("", "uint8_t")]},
     "dm_comm_create_rccl": {"id128": [("", "uint8_t")]},
     "dm_comm_all_gather_v": {"send": [("", "uint8_t")], "recv": [("", "uint8_t")]},
@@ -46,6 +52,22 @@ VOID_HOST = {
 }
 FIXED = {("dm_load_weights_din", "F32"): {"dtype": "DM_F32"}, ("dm_load_weights_din", "F64"): {"dtype": "DM_F64"}}   # args the variant pins
 HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: written out below
+# entry points that neither wait on peers / the network nor run a long device job: the only ones allowed a Critical region
+CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_memcpy_h2d", "dm_memcpy_d2h", "dm_kernel_timing_get",
+               "dm_kernel_timing_get_kind", "dm_get_scorer_mode", "dm_comm_rank", "dm_device_count", "dm_last_scored_rows",
+               "dm_train_last_loss", "dm_train_sync_stats", "dm_comm_unique_id", "dm_dev_alloc", "dm_create"}
+JTYPE = {"jint": "Int", "jlong": "Long", "jfloat": "Float", "jdouble": "Double", "jbyte": "Byte"}
+
+
+def pin(cname, je, an, const):
+    """(acquire, release) statements for the host array `an` of JNI element type `je`."""
+    mode = "JNI_ABORT" if const else "0"
+    if cname in CRITICAL_OK:
+        return ("  %s *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (je, an, an, an),
+                "  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, %s);" % (an, an, an, mode))
+    t = JTYPE[je]
+    return ("  %s *p_%s = %s ? (*e)->Get%sArrayElements(e, %s, 0) : 0;" % (je, an, an, t, an),
+            "  if (p_%s) (*e)->Release%sArrayElements(e, %s, p_%s, %s);" % (an, t, an, an, mode))
 
 
 def camel(name):
@@ -92,7 +114,7 @@ def gen(protos):
     c, sc = [], []
     for meth, cname, ret, args, voids in expand(protos):
         jparams, sparams, pre, post, call = [], [], [], [], []
-        handle_expr = "0"
+        handle_expr, comm_expr = "0", None
         for i, a in enumerate(args):
             base, ptr, an, const = a["base"], a["ptr"], a["name"], a["const"]
             if an in voids.get("__fixed__", {}):
@@ -102,10 +124,12 @@ def gen(protos):
                 call.append("(%s)(intptr_t)%s" % (base, an))
                 if base == "dm_handle_t" and i == 0:
                     handle_expr = "(dm_handle_t)(intptr_t)%s" % an
+                if base == "dm_comm_t" and i == 0:
+                    comm_expr = "(dm_comm_t)(intptr_t)%s" % an
             elif base in ("dm_handle_t", "dm_comm_t") and ptr == "*":      # out handle(s) or a list of handles
                 jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
-                pre.append("  jlong *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (an, an, an))
-                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, 0);" % (an, an, an))
+                a_, r_ = pin(cname, "jlong", an, False)
+                pre.append(a_); post.append(r_)
                 call.append("(%s *)p_%s" % (base, an))
             elif base in STRUCTS and ptr == "*":
                 fields = STRUCTS[base]
@@ -121,14 +145,14 @@ def gen(protos):
             elif base == "void" and ptr == "*" and an in voids:               # host buffer of a known element type
                 jt, je, st = ARRAY[voids[an]]
                 jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
-                pre.append("  %s *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (je, an, an, an))
-                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, %s);" % (an, an, an, "JNI_ABORT" if const else "0"))
+                a_, r_ = pin(cname, je, an, const)
+                pre.append(a_); post.append(r_)
                 call.append("p_%s" % an)
             elif ptr in ("*", "**") and (base == "void" or an.startswith("d_") or an == "dptr"):   # device pointers travel as jlong
                 if ptr == "**" or (base != "void" and an in ("d_ptr",)) or an == "dptr":
                     jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
-                    pre.append("  jlong *p_%s = (*e)->GetPrimitiveArrayCritical(e, %s, 0);" % (an, an))
-                    post.append("  (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, 0);" % (an, an))
+                    a_, r_ = pin(cname, "jlong", an, False)
+                    pre.append(a_); post.append(r_)
                     call.append("(%s %s)p_%s" % (base, ptr, an))
                 else:
                     jparams.append("jlong %s" % an); sparams.append("%s: Long" % an)
@@ -136,8 +160,8 @@ def gen(protos):
             elif ptr == "*" and base in ARRAY:
                 jt, je, st = ARRAY[base]
                 jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
-                pre.append("  %s *p_%s = %s ? (*e)->GetPrimitiveArrayCritical(e, %s, 0) : 0;" % (je, an, an, an))
-                post.append("  if (p_%s) (*e)->ReleasePrimitiveArrayCritical(e, %s, p_%s, %s);" % (an, an, an, "JNI_ABORT" if const else "0"))
+                a_, r_ = pin(cname, je, an, const)
+                pre.append(a_); post.append(r_)
                 call.append("(%s%s *)p_%s" % ("const " if const else "", base, an))
             elif ptr == "" and base in SCALAR:
                 jparams.append("%s %s" % (SCALAR[base][0], an)); sparams.append("%s: %s" % (an, SCALAR[base][1]))
@@ -157,7 +181,10 @@ def gen(protos):
         else:
             body.append("  const int rc_ = %s;" % callexpr)
             body += post[::-1]
-            body.append("  (void)cls; if (rc_) raise(e, %s, rc_);" % handle_expr)
+            if comm_expr or (cname.startswith("dm_comm_create") or cname == "dm_comm_unique_id"):
+                body.append("  (void)cls; if (rc_) raise_comm(e, %s, rc_);" % (comm_expr or "0"))     # communicator calls: dm_comm_last_error
+            else:
+                body.append("  (void)cls; if (rc_) raise(e, %s, rc_);" % handle_expr)
         body.append("}")
         c.append("\n".join(body))
         sc.append("  @native def %s(%s): %s" % (meth, ", ".join(sparams), sret))
@@ -175,14 +202,16 @@ C_HEAD = '''/* dismember_jni.c — JNI shim over include/dismember_hip.h: one na
 #include "dismember_hip.h"
 
 /* a non-zero status becomes the exception the Scala code threw at that point */
-static void raise(JNIEnv *e, dm_handle_t h, int rc) {
+static void raise_msg(JNIEnv *e, int rc, const char *msg) {
   const char *cls = rc == DM_ERR_INDEX ? "java/lang/ArrayIndexOutOfBoundsException"      /* LookupTable.scala:47-53 */
                   : rc == DM_ERR_INVALID ? "java/lang/IllegalArgumentException"           /* require(...) */
                   : rc == DM_ERR_STATE ? "java/lang/IllegalStateException"
                   : rc == DM_ERR_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/RuntimeException";
-  const char *msg = dm_last_error(h);
   (*e)->ThrowNew(e, (*e)->FindClass(e, cls), msg && *msg ? msg : "dismember_hip call failed");
 }
+static void raise(JNIEnv *e, dm_handle_t h, int rc) { raise_msg(e, rc, dm_last_error(h)); }
+/* communicator entry points keep their message in the communicator (NULL: the last create-time error) */
+static void raise_comm(JNIEnv *e, dm_comm_t c, int rc) { raise_msg(e, rc, dm_comm_last_error(c)); }
 '''
 
 C_DR = '''
