@@ -90,6 +90,9 @@ def parse():
                     help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode; auto = the library default)")
     ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=1024, help="users for recall@topk vs brute force (0 skip)")
+    ap.add_argument("--jtm-full", type=int, default=1, help="also time the FULL JTM.optimize over the 10M-item catalogue (BASELINE configs[3]); 0 = skip")
+    ap.add_argument("--jtm-rows", type=int, default=4, help="training rows per item of the full JTM.optimize extra")
+    ap.add_argument("--otm64", type=int, default=1, help="also time OTM serving and one OTM training iteration in the reference's fp64 (BASELINE configs[2]); 0 = skip")
     a = ap.parse_args()
     if a.big is not None:
         a.small = a.big
@@ -447,6 +450,38 @@ def main():
                            "= %d DIN rows per worker; pairs expanded, scored and summed (reference-order fp32) on the device, host buffers in and out" % (ni_j, ni_j * 4 * 6),
                "items_per_s": world * ni_j / dtj, "din_rows_per_s": world * ni_j * 24 / dtj, "ms": dtj * 1e3,
                "finite_weights": bool(np.isfinite(wj).all())}
+    # ---- extra: the FULL JTM.optimize over the catalogue (BASELINE configs[3]: every gap step from the root to the leaves, scoring on
+    #      the device, greedy re-balance per parent node), items sharded over the ranks when there are several ----
+    jtm_full = None
+    if a.small and default_cfg and a.jtm_full:
+        from dismember_amd.jtm import JTM
+        order = np.argsort(tree["leaf_ids"], kind="stable")
+        items_s = tree["leaf_ids"][order]; codes_s = tree["leaf_codes"][order]
+        nrow = int(a.jtm_rows)
+        t0 = time.perf_counter()
+        hist = seqs[:min(a.users, 262144)]
+        pick = np.random.default_rng(synth.SEED + 77).integers(0, len(hist), size=items_s.size * nrow)
+        row_ids = hist[pick].reshape(-1)
+        row_off = np.arange(items_s.size + 1, dtype=np.int64) * nrow
+        jtf = JTM.from_arrays(eng, items_s, codes_s, depth, row_off, row_ids, gap=2, seq_len=L, comm=None)
+        prep = time.perf_counter() - t0
+        sync(); barrier()
+        tim = {}
+        t0 = time.perf_counter()
+        projf = jtf.optimize(timing=tim, as_array=True)
+        sync(); barrier()
+        dtf = max_over_ranks(time.perf_counter() - t0)
+        first_leaf = (1 << depth) - 1
+        steps_j = (depth + 1) // 2
+        din_rows = int(items_s.size) * nrow * 6 * steps_j
+        jtm_full = {"workload": "JTM.optimize, %d items x %d training rows, depth-%d tree, gap 2: %d gap steps, %d DIN rows scored "
+                                "(6 chain nodes per row and step); every rank runs the whole re-assignment on its own GPU (replicas)"
+                                % (items_s.size, nrow, depth, steps_j, din_rows),
+                    "seconds": dtf, "items_per_s": world * items_s.size / dtf, "din_rows_per_s": world * din_rows / dtf,
+                    "scoring_s": tim.get("scoring_s"), "rebalance_s": tim.get("rebalance_s"), "host_glue_s": tim.get("host_glue_s"),
+                    "host_preparation_s": prep,
+                    "bijection_onto_leaves": bool(np.unique(projf).size == projf.size and int(projf.min()) >= first_leaf)}
+        del jtf, row_ids, pick, projf
     # ---- extra: BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel training step on it ----
     small = train = None
     if a.small and default_cfg:
@@ -600,6 +635,76 @@ def main():
             dr["cpu_baseline"] = {"value": len(cs) / dtc, "unit": "users/s", "cores": 1, "kind": "port",
                                   "sample": "%d users, fp64 oracle beam search (same D, K, beam, E, L; %d-item catalogue: the work per "
                                             "user does not depend on the catalogue size), 1 thread" % (len(cs), small_items)}
+    # ---- extra: BASELINE configs[2] in the reference's own arithmetic: the OTM scorer is DIN[Double] (otm/.../model/DIN.scala:12-39).
+    #      fp64 model over the complete depth-24 tree (34.4 GB table), serving on the fused fp64 beam kernel, then ONE
+    #      LocalOptimizer iteration (otm/.../optim/LocalOptimizer.scala:55-109): pseudo targets, beam nodes, and per level a
+    #      forward/backward + gradient exchange + dense fp64 Adam over all 4.29 G parameters ----
+    otm64 = None
+    if a.otm64 and default_cfg:
+        try:
+            eng.close()
+        except Exception:
+            pass
+        eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+        try:
+            depth6 = 24
+            ni6 = (1 << (depth6 + 1)) - 1
+            eng.load_weights_din_synthetic_f64(E, ni6, synth.SEED)
+            first6 = (1 << depth6) - 1
+            orng = np.random.default_rng(synth.SEED + 606 + rank)
+            Uo6 = 16384
+            oc6 = (first6 + orng.integers(0, 1 << depth6, size=(Uo6, L))).astype(np.int32)
+            oc6[orng.random((Uo6, L)) < 0.15] = -1
+            d_s6 = eng.dev_alloc(Uo6 * L * 4); d_i6 = eng.dev_alloc(Uo6 * 2 * a.beam * 4); d_c6 = eng.dev_alloc(Uo6 * 2 * a.beam * 4); d_n6 = eng.dev_alloc(Uo6 * 4)
+            eng.h2d(d_s6, oc6)
+            eng.otm_beam_search_dev(d_s6, 2048, L, a.beam, depth6, d_i6, d_c6, d_n6)
+            sync(); eng.timing_reset(); barrier()
+            t0 = time.perf_counter()
+            eng.otm_beam_search_dev(d_s6, Uo6, L, a.beam, depth6, d_i6, d_c6, d_n6)
+            sync(); barrier()
+            dt6 = max_over_ranks(time.perf_counter() - t0)
+            nl6, kms6 = eng.timing_get()
+            rows6 = eng.last_scored_rows()
+            fl6 = rows6 * 2.0 * (E * E + 2 * L * E + E)
+            otm64 = {"workload": "OTM beam-search serving in fp64 (the reference's DIN[Double]): complete depth-%d tree (%d nodes x %d doubles = %.1f GB), "
+                                 "beam=%d, request and results resident in HBM" % (depth6, ni6, E, ni6 * E * 8 / 1e9, a.beam),
+                     "scorer": eng.scorer_mode()["mode"], "kernel": eng.last_beam_kernel(), "users_per_call": Uo6,
+                     "users_per_s": world * Uo6 / dt6, "kernel_ms": kms6, "scored_rows_per_user": rows6 / Uo6,
+                     "roofline": {"bound": "mfma", "dtype": "f64", "achieved": fl6 / (kms6 * 1e-3) / 1e12 if kms6 else None, "peak": 78.6,
+                                  "unit": "TFLOP/s", "frac": (fl6 / (kms6 * 1e-3) / 78.6e12) if kms6 else None,
+                                  "flop_per_row": 2 * (E * E + 2 * L * E + E)}}
+            for d_ in (d_s6, d_i6, d_c6, d_n6):
+                eng.dev_free(d_)
+            # one training iteration in fp64
+            from dismember_amd.otm_train import OTMTrainer
+            comm6 = None
+            if dist is not None:
+                if comm is None:
+                    comm, comm_transport, comm_err = make_comm(dist, rank, world, local)
+                comm6 = comm
+            t0 = time.perf_counter()
+            tr6 = OTMTrainer(eng, depth6, a.beam, seq_len=L, lr=1e-4, comm=comm6)
+            sync()
+            t_init6 = time.perf_counter() - t0
+            Ut6 = 20                                   # 20 users x 400 candidates = 8000 rows per level (model.total_batch_size 8192)
+            tseq6 = oc6[:Ut6]
+            ttg6 = [(first6 + orng.integers(0, 1 << depth6, size=2)).tolist() for _ in range(Ut6)]
+            tr6.train_batch(tseq6, ttg6)
+            sync(); barrier()
+            t0 = time.perf_counter()
+            losses6 = tr6.train_batch(tseq6, ttg6)
+            sync(); barrier()
+            dtt6 = max_over_ranks(time.perf_counter() - t0)
+            npar6 = ni6 * E + 3 * E * E + 2 * E + 1
+            otm64["train_iteration"] = {
+                "workload": "one OTM LocalOptimizer iteration in fp64: %d users per worker, pseudo targets + beam nodes, then %d levels x "
+                            "(forward/backward on %d rows, gradient exchange, dense fp64 Adam over %d parameters)"
+                            % (Ut6, len(losses6), Ut6 * 2 * a.beam, npar6),
+                "seconds": dtt6, "levels": len(losses6), "loss_first_level": float(losses6[0]), "loss_last_level": float(losses6[-1]),
+                "adam_stream_bytes_per_level": 8 * 8 * npar6, "train_init_s": t_init6, "workers": world,
+                "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker"}
+        except Exception as ex:
+            otm64 = dict(otm64 or {}, error=repr(ex))
     # ---- extra: BASELINE configs[0]'s own timer (examples/.../tdm/package.scala:119-123 prints "Average recommend time"): the bundled
     #      trained E=16 model + tree, one user per call, topk 10, beam 20, 10 warm-up + 100 timed calls through the facade ----
     c1 = None
@@ -642,6 +747,63 @@ def main():
                   "recall_vs_bruteforce_trained_model": dict(rec1, users=len(q1s),
                                                              definition="|beam top-k  ∩  brute-force top-k| / k on the bundled trained DIN (tests/golden/din_f32.npy)")}
             e1.close()
+            # the reference's other two serving timers: OTM (examples/.../otm/package.scala:101-105) on the bundled trained DIN[Double] +
+            # item -> leaf mapping, and Deep-Retrieval (examples/.../dr/package.scala:107-111; its bundled model is not in the checkout:
+            # a synthetic fp64 model over the bundled item -> path mapping, K = 100, D = 3, E = 16)
+            try:
+                from dismember_amd import OTM as OTMFacade
+                w6 = np.load(os.path.join(gdir, "din_f64.npy")); om = np.load(os.path.join(gdir, "otm_mapping.npy"))
+                e2 = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+                e2.load_weights_din(w6, 16, 8191)
+                mo = OTMFacade(e2, {int(a_): int(b_) for a_, b_ in om})
+                qo = [int(x) for x in om[:10, 0]]
+                for _ in range(10):
+                    mo.recommend(qo, 10, 20)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    mo.recommend(qo, 10, 20)
+                dto2 = (time.perf_counter() - t0) / 100
+                od6 = po.Din(w6, 16, 10, 8191)
+                qc = np.array([mo.item_id_mapping[i] for i in qo], np.int32)
+                po.otm_beam_search(od6, qc, mo.leaf_level, 20)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    oi6, os6 = po.otm_beam_search(od6, qc, mo.leaf_level, 20)
+                    po.otm_finalize(oi6, os6, mo._node_to_item, 10)
+                dtoo = (time.perf_counter() - t0) / 100
+                c1["otm_recommend"] = {"workload": "OTM.recommend(sequence, topk=10, beamSize=20) on the bundled trained DIN[Double] (fp64 arithmetic on both sides), one user per call, 10 + 100 calls",
+                                       "ms_per_call": dto2 * 1e3, "cpu_oracle_ms_per_call": dtoo * 1e3, "kernel": e2.last_beam_kernel()}
+                e2.close()
+                from dismember_amd import DeepRetrieval as DRFacade
+                dm_ = np.load(os.path.join(gdir, "dr_mapping.npz"))
+                nit = int(dm_["ids"].max()) + 1
+                wdr = synth.make_dr_model(nit, 100, 3, 10, 16, np.random.default_rng(11), scale=0.3)
+                ip = np.zeros((nit, dm_["paths"].shape[1], 3), np.int32); ip[dm_["ids"]] = dm_["paths"]
+                pit = synth.dr_path_items(ip)
+                e3 = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+                e3.dr_load_model(wdr, 16, 10, 100, 3, nit, dtype=np.float64)
+                e3.dr_load_path_items(*pit)
+                md = DRFacade(e3, {int(i_): int(d_) for i_, d_ in zip(dm_["items"], dm_["ids"])})
+                qd = [int(x) for x in dm_["items"][:10]]
+                for _ in range(10):
+                    md.recommend(qd, 10, 20)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    md.recommend(qd, 10, 20)
+                dtd = (time.perf_counter() - t0) / 100
+                odr = po.DeepRetrieval(wdr, 16, 10, 100, 3, nit, path_items=pit)
+                qdi = np.array([md.item_id_mapping[i] for i in qd], np.int32)
+                odr.recommend(qdi, 10, 20)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    odr.recommend(qdi, 10, 20)
+                dtdo = (time.perf_counter() - t0) / 100
+                c1["dr_recommend"] = {"workload": "DeepRetrieval.recommend(sequence, topk=10, beamSize=20): synthetic fp64 model (K=100, D=3, E=16) over the bundled "
+                                                  "item -> path mapping (%d items x 2 paths), one user per call, 10 + 100 calls" % nit,
+                                      "ms_per_call": dtd * 1e3, "cpu_oracle_ms_per_call": dtdo * 1e3}
+                e3.close()
+            except Exception as ex:
+                c1["other_timers_skipped"] = repr(ex)
         except Exception as ex:       # the fixtures are test data: their absence must not break the bench line
             c1 = {"skipped": repr(ex)}
     if rank == 0:
@@ -655,6 +817,10 @@ def main():
             res_main["extra_otm_serve"] = otm
         if jtm is not None:
             res_main["extra_jtm_scoring"] = jtm
+        if jtm_full is not None:
+            res_main["extra_jtm_optimize"] = jtm_full
+        if otm64 is not None:
+            res_main["extra_otm_fp64"] = otm64
         if small is not None:
             res_main["extra_1m_item_tree"] = small
         if train is not None:

@@ -104,6 +104,7 @@ SIGNATURES = {
     "dm_fill_normal_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
     "dm_fill_tree_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64]),
     "dm_load_weights_din_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
+    "dm_load_weights_din_dev_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "dm_set_scorer_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dm_get_scorer_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dm_otm_beam_search_f64": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double), i32p]),

@@ -541,6 +541,32 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
   return DM_OK;
 }
 
+// the fp64 counterpart (the reference's OTM model is DIN[Double]): same ownership rule; the f32 copy of the table that the
+// throughput-mode beam kernels read is made here
+int dm_load_weights_din_dev_f64(dm_handle_t h, int E, int64_t num_index, double *d_compact, int64_t n_elems) {
+  if (!h) return DM_ERR_INVALID;
+  if (!d_compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev_f64: bad arguments");
+  if (E != 16 && E != 32 && E != 64 && E != 128) return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din_dev_f64: embed size must be 16, 32, 64 or 128");
+  const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
+  if (need != n_elems) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev_f64: n_elems does not match the DIN layout for (E, num_index)");
+  HIPCHK(h, hipSetDevice(h->device));
+  free_weights(h);
+  h->dtype = DM_F64;
+  h->d_compact = d_compact;
+  ALLOC(h, h->d_emb32, (size_t)num_index * E * 4);
+  h->emb32_owned = true;
+  hipLaunchKernelGGL(dm_f64_to_f32_kernel, dim3(4096), dim3(256), 0, h->stream, (const double *)d_compact, h->d_emb32, num_index * E);
+  HIPCHK(h, hipGetLastError());
+  const int64_t tail = n_elems - num_index * E;
+  std::vector<double> t((size_t)tail);
+  HIPCHK(h, hipMemcpy(t.data(), d_compact + num_index * E, (size_t)tail * 8, hipMemcpyDeviceToHost));
+  int rc = upload_derived<double>(h, E, t.data());
+  if (rc != DM_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  return DM_OK;
+}
+
 template <typename T>
 __global__ void dm_fill_normal_kernel(T *out, int64_t n, float mean, float std, unsigned long long seed) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;

@@ -99,9 +99,29 @@ class Engine:
         self._synth_ptr, self._synth_n = d, n
         return d
 
+    def load_weights_din_synthetic_f64(self, E, num_index, seed, small=None):
+        """The fp64 counterpart (the reference's OTM model type): the table holds the f32 draws widened to double
+        (dm_fill_normal_f64), the small matrices come from `small` (defaults to the reference init) as doubles."""
+        n = num_index * E + 3 * E * E + 2 * E + 1
+        d = self.dev_alloc(n * 8)
+        self._chk(N.lib().dm_fill_normal_f64(self._h, d, num_index * E, 0.0, 0.05, int(seed)))
+        if small is None:
+            rng = np.random.default_rng(int(seed))
+            small = np.zeros(3 * E * E + 2 * E + 1, np.float32)
+            small[:3 * E * E] = rng.standard_normal(3 * E * E, dtype=np.float32) * 0.05
+            small[3 * E * E + E:3 * E * E + 2 * E] = rng.standard_normal(E, dtype=np.float32) * 0.05
+        small = np.ascontiguousarray(small, dtype=np.float64)
+        assert small.size == 3 * E * E + 2 * E + 1
+        self._chk(N.lib().dm_memcpy_h2d(self._h, C.c_void_p(d.value + num_index * E * 8),
+                                        small.ctypes.data_as(C.c_void_p), small.nbytes))
+        self._chk(N.lib().dm_load_weights_din_dev_f64(self._h, int(E), int(num_index), d, n))
+        self.E, self.dtype, self.num_index = int(E), np.dtype(np.float64), int(num_index)
+        self._synth_ptr, self._synth_n = d, n
+        return d
+
     def download_weights(self):
         """Host copy of the compact vector built by load_weights_din_synthetic (for the CPU oracle)."""
-        out = np.empty(self._synth_n, np.float32)
+        out = np.empty(self._synth_n, self.dtype)
         self.d2h(out, self._synth_ptr)
         return out
 

@@ -34,6 +34,23 @@ class JTM:
         self.row_off = off
         self.row_ids = _i32(np.concatenate(rows)) if off[-1] > 0 else np.zeros(self.L, np.int32)
 
+    @classmethod
+    def from_arrays(cls, engine, items_sorted, item_code, max_level, row_off, row_ids, gap=2, seq_len=10, hierarchical=False,
+                    min_level=0, use_mask=True, comm=None):
+        """The same object from flat arrays (catalogue-scale runs: no per-item Python objects): items in ascending id order,
+        item_code[k] the current leaf code of items_sorted[k], row_off [n+1] / row_ids [rows * seq_len] the CSR of the items'
+        training rows (itemSequenceMap)."""
+        o = cls.__new__(cls)
+        o.engine = engine
+        o.items = _i32(items_sorted); o.item_code = _i32(item_code)
+        o.max_level, o.gap, o.L = int(max_level), int(gap), int(seq_len)
+        o.hierarchical, o.min_level, o.use_mask = bool(hierarchical), int(min_level), bool(use_mask)
+        o.comm = comm
+        o.row_off = np.ascontiguousarray(row_off, np.int64)
+        o.row_ids = _i32(row_ids)
+        assert o.row_off.size == o.items.size + 1 and o.row_ids.size >= int(o.row_off[-1]) * o.L
+        return o
+
     def weights_range(self, item_node, old_level, level, lo, hi):
         """TreeLearning.aggregateWeights for the items [lo, hi) of the ascending-id item list (their rows only)."""
         nchild = 1 << (level - old_level)
@@ -75,18 +92,30 @@ class JTM:
                 return c.astype(np.int32)
             c[m] = (c[m] - 1) >> 1
 
-    def optimize(self, weight_fn=None):
+    def optimize(self, weight_fn=None, timing=None, as_array=False):
         """JTM.optimize (JTM.scala:22-73).  weight_fn(item_node, old_level, level) -> [n, 2^gap] overrides the GPU
-        scorer (parity tests feed the oracle's weights through the same assignment logic)."""
+        scorer (parity tests feed the oracle's weights through the same assignment logic).  timing: dict that receives the
+        seconds spent in scoring (dm_jtm_child_weights incl. its copies), re-balance (dm_jtm_rebalance_all) and host glue."""
+        import time
         proj = np.zeros(self.items.size, np.int32)            # first all assigned to the root (:23-26)
+        t_sc = t_rb = t_host = 0.0
         for old_level in range(0, self.max_level, self.gap):
             level = min(self.max_level, old_level + self.gap)
+            t0 = time.perf_counter()
             w = (weight_fn or self.child_weights)(proj, old_level, level)
+            t1 = time.perf_counter()
             old_node = self.ancestor_at_level(self.item_code, level)
             max_assign = 1 << (self.max_level - level)         # TreeLearning.scala:56
             w = np.ascontiguousarray(w, np.float32)
             new = np.empty_like(proj)                          # every parent node of the level in one call
+            t2 = time.perf_counter()
             self.engine._chk(N.lib().dm_jtm_rebalance_all(self.engine._h, _p(w, N.f32p), _p(_i32(old_node), N.i32p), _p(proj, N.i32p),
                                                           proj.size, old_level, level, int(max_assign), _p(new, N.i32p)))
+            t3 = time.perf_counter()
+            t_sc += t1 - t0; t_host += t2 - t1; t_rb += t3 - t2
             proj = new
+        if timing is not None:
+            timing.update(scoring_s=t_sc, rebalance_s=t_rb, host_glue_s=t_host)
+        if as_array:
+            return proj
         return dict(zip(self.items.tolist(), proj.tolist()))

@@ -377,6 +377,8 @@ int dm_fill_tree_normal(dm_handle_t h, float *d_emb, int E, int depth, float rho
 /* like dm_load_weights_din(DM_F32) but the compact vector already lives in device memory; the handle
  * takes ownership of d_compact (freed with the handle / on the next load). */
 int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_compact, int64_t n_elems);
+/* the same for an fp64 model (dm_load_weights_din(DM_F64): the reference's OTM scorer is DIN[Double]) */
+int dm_load_weights_din_dev_f64(dm_handle_t h, int E, int64_t num_index, double *d_compact, int64_t n_elems);
 
 /* ---- measurement ----------------------------------------------------------- */
 /* HIP events on the handle's stream around every beam-search kernel launched since the last
