@@ -369,9 +369,9 @@ def main():
         # cannot run inside this process; the committed per-launch figure is attached when it was measured on
         # this exact workload, otherwise traffic stays null.
         try:
-            pname = "r02_summary.json" if mode != "f32" else "r02_f32_summary.json"
+            pname = "r03_summary.json" if mode != "f32" else "r03_f32_summary.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
-            pw = prof["bench_line_under_profiler"]["config"]
+            pw = (prof.get("bench_lines_under_profiler") or [prof.get("bench_line_under_profiler")])[0]["config"]
             if pw["workload"] == res["config"]["workload"] and pw["users_per_step_per_gpu"] == U and kern_name in prof["kernel_trace"]["kernel"]:
                 res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
                 res["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch, "

@@ -84,13 +84,9 @@ class JTM:
     @staticmethod
     def ancestor_at_level(codes, level):
         """JTMTree.getAncestorAtLevel (JTMTree.scala:36-43), vectorised over codes."""
-        c = np.asarray(codes, np.int64).copy()
-        lim = (1 << (level + 1)) - 1
-        while True:
-            m = c >= lim
-            if not m.any():
-                return c.astype(np.int32)
-            c[m] = (c[m] - 1) >> 1
+        c1 = np.asarray(codes, np.int64) + 1                    # heap code + 1 = 1 b_1 b_2 ...: its bit length is level + 1
+        lv = np.frexp(c1.astype(np.float64))[1] - 1             # exact below 2^53
+        return ((c1 >> np.maximum(lv - level, 0)) - 1).astype(np.int32)
 
     def optimize(self, weight_fn=None, timing=None, as_array=False):
         """JTM.optimize (JTM.scala:22-73).  weight_fn(item_node, old_level, level) -> [n, 2^gap] overrides the GPU

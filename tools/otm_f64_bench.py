@@ -24,7 +24,8 @@ else:
 d_seq = eng.dev_alloc(seqs.nbytes); eng.h2d(d_seq, seqs)
 d_ids = eng.dev_alloc(U * 2 * beam * 4); d_sc = eng.dev_alloc(U * 2 * beam * 4); d_cnt = eng.dev_alloc(U * 4)
 rows_per_user = 2 * (1 << (beam.bit_length() - 1)) + (depth - beam.bit_length()) * 2 * beam
-for mode in ("f64", "f32", "split_f16"):
+modes = ("f64",) if (len(sys.argv) > 3 and sys.argv[3] == "f64only") else ("f64", "f32", "split_f16")
+for mode in modes:
     eng.set_scorer_mode(mode)
     eng.otm_beam_search_dev(d_seq, min(U, 1024), L, beam, depth, d_ids, d_sc, d_cnt); eng.synchronize()
     eng.timing_reset()
