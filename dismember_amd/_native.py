@@ -64,6 +64,8 @@ SIGNATURES = {
     "dm_tdm_bruteforce_topk": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, f32p, i32p]),
     "dm_jtm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, f32p]),
+    "dm_jtm_cache_rows": (C.c_int, [C.c_void_p, i64p, i32p, C.c_int64, C.c_int]),
+    "dm_jtm_child_weights_cached": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     "dm_jtm_rebalance": (C.c_int, [C.c_void_p, f32p, i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]),
     "dm_jtm_rebalance_all": (C.c_int, [C.c_void_p, f32p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p]),
     "dm_otm_rebalance_all": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p]),
@@ -105,6 +107,8 @@ SIGNATURES = {
     "dm_fill_tree_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64]),
     "dm_load_weights_din_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
     "dm_load_weights_din_dev_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64]),
+    "dm_save_model": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "dm_load_model": (C.c_int, [C.c_void_p, C.c_char_p]),
     "dm_set_scorer_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dm_get_scorer_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dm_otm_beam_search_f64": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double), i32p]),

@@ -115,6 +115,11 @@ struct dm_ctx {
   // multi-GPU exchange (comm.hip.inc): the attached communicator (not owned) and the staging area of dm_train_sync_gradients
   void *d_defer = nullptr;       // users the W kernel hands to the LDS-fed kernel: [count u64 | queue head u64 | ids]
   size_t defer_bytes = 0;
+  // JTM: the catalogue's training rows kept on the device across gap steps (dm_jtm_cache_rows)
+  int64_t *d_jtm_off = nullptr;
+  int32_t *d_jtm_ritem = nullptr, *d_jtm_rids = nullptr;
+  std::vector<int64_t> jtm_off;
+  int jtm_L = 0;
   struct dm_comm *comm = nullptr;
   void *d_sync = nullptr;
   size_t sync_bytes = 0;
@@ -327,6 +332,7 @@ int dm_destroy(dm_handle_t h) {
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer); dm_free_ptr(h->d_scratch64);
+  dm_free_ptr(h->d_jtm_off); dm_free_ptr(h->d_jtm_ritem); dm_free_ptr(h->d_jtm_rids);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1449,6 +1455,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "dr_host.hip.inc"
 #include "otm64.hip.inc"
 #include "comm.hip.inc"
+#include "checkpoint.hip.inc"
 
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {

@@ -1,5 +1,6 @@
 """Thin object wrapper over the C ABI: one Engine == one dm_handle_t (device + stream)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -118,6 +119,20 @@ class Engine:
         self.E, self.dtype, self.num_index = int(E), np.dtype(np.float64), int(num_index)
         self._synth_ptr, self._synth_n = d, n
         return d
+
+    def save_model(self, path):
+        """TDM.saveModel (T/model/TDM.scala:32-41): weights + index in one flat file (dm_save_model)."""
+        self._chk(N.lib().dm_save_model(self._h, os.fsencode(path)))
+
+    def load_model(self, path):
+        """TDM.loadModel: replaces the handle's tree, id maps and weights with the checkpoint's."""
+        self._chk(N.lib().dm_load_model(self._h, os.fsencode(path)))
+        import struct
+        with open(path, "rb") as f:
+            hd = f.read(8 + 8 * 4 + 4 * 8)
+        _, dtype, E, _, _, _, _, _ = struct.unpack("<8i", hd[8:40])
+        num_index, = struct.unpack("<q", hd[40:48])
+        self.E, self.dtype, self.num_index = int(E), np.dtype(np.float64 if dtype == 1 else np.float32), int(num_index)
 
     def download_weights(self):
         """Host copy of the compact vector built by load_weights_din_synthetic (for the CPU oracle)."""

@@ -32,6 +32,16 @@ class TDM:
         out = [list(zip(ids[u, :cnt[u]].tolist(), prob[u, :cnt[u]].tolist())) for u in range(ids.shape[0])]
         return out[0] if single else out
 
+    def save_model(self, model_path):
+        """TDM.saveModel (TDM.scala:32-41): one flat checkpoint instead of a Java-serialised module graph."""
+        self.engine.save_model(model_path)
+
+    @classmethod
+    def load_model(cls, engine, path, model_name="din"):
+        """TDM.loadModel (TDM.scala:43-54)."""
+        engine.load_model(path)
+        return cls(engine, model_name)
+
     def recommend_items(self, sequence, topk, candidate_num, consumed_items=None):
         """Recommender.recommendItems (Recommender.scala:18-37): ids only, beam widened by consumed count."""
         seq = np.asarray(sequence, dtype=np.int32)

@@ -59,6 +59,11 @@ class JTM:
         w = np.empty((max(n, 1), nchild), np.float32)
         if n == 0:
             return w[:0]
+        if getattr(self, "_cached", False):          # rows already on the device (optimize): only the node list goes up
+            sub = np.ascontiguousarray(node[lo:hi])
+            self.engine._chk(N.lib().dm_jtm_child_weights_cached(self.engine._h, _p(sub, N.i32p), lo, n, old_level, level,
+                                                                 int(self.hierarchical), self.min_level, int(self.use_mask), _p(w, N.f32p)))
+            return w[:n]
         off = np.ascontiguousarray(self.row_off[lo:hi + 1] - self.row_off[lo])
         r0, r1 = int(self.row_off[lo]), int(self.row_off[hi])
         rows = np.ascontiguousarray(self.row_ids[r0 * self.L:max(r1, r0 + 1) * self.L])
@@ -95,12 +100,31 @@ class JTM:
         import time
         proj = np.zeros(self.items.size, np.int32)            # first all assigned to the root (:23-26)
         t_sc = t_rb = t_host = 0.0
+        t0 = time.perf_counter()
+        if weight_fn is None and self.row_off[0] == 0:         # itemSequenceMap goes to the device once for all gap steps
+            self.engine._chk(N.lib().dm_jtm_cache_rows(self.engine._h, _p(self.row_off, N.i64p), _p(self.row_ids, N.i32p), self.items.size, self.L))
+            self._cached = True
+        t_up = time.perf_counter() - t0
+        try:
+            return self._optimize(proj, weight_fn, timing, as_array, t_up)
+        finally:
+            if getattr(self, "_cached", False):
+                self._cached = False
+                self.engine._chk(N.lib().dm_jtm_cache_rows(self.engine._h, None, None, 0, self.L))
+
+    def _optimize(self, proj, weight_fn, timing, as_array, t_up):
+        import time
+        t_sc = t_rb = t_host = 0.0
+        c1 = lv = None
         for old_level in range(0, self.max_level, self.gap):
             level = min(self.max_level, old_level + self.gap)
             t0 = time.perf_counter()
             w = (weight_fn or self.child_weights)(proj, old_level, level)
             t1 = time.perf_counter()
-            old_node = self.ancestor_at_level(self.item_code, level)
+            if c1 is None:                                     # the items' codes do not change during a run: level of each, once
+                c1 = self.item_code.astype(np.int64) + 1
+                lv = (np.frexp(c1.astype(np.float64))[1] - 1).astype(np.int64)
+            old_node = ((c1 >> np.maximum(lv - level, 0)) - 1).astype(np.int32)     # JTMTree.getAncestorAtLevel
             max_assign = 1 << (self.max_level - level)         # TreeLearning.scala:56
             w = np.ascontiguousarray(w, np.float32)
             new = np.empty_like(proj)                          # every parent node of the level in one call
@@ -111,7 +135,7 @@ class JTM:
             t_sc += t1 - t0; t_host += t2 - t1; t_rb += t3 - t2
             proj = new
         if timing is not None:
-            timing.update(scoring_s=t_sc, rebalance_s=t_rb, host_glue_s=t_host)
+            timing.update(scoring_s=t_sc, rebalance_s=t_rb, host_glue_s=t_host, rows_upload_s=t_up)
         if as_array:
             return proj
         return dict(zip(self.items.tolist(), proj.tolist()))

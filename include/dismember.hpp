@@ -108,6 +108,9 @@ class Engine {
     check(dm_load_weights_din(h_, DM_F64, embedSize, numIndex, compact.data(), (int64_t)compact.size()));
     embed_ = embedSize;
   }
+  // TDM.saveModel / TDM.loadModel (tdm/.../model/TDM.scala:32-54): weights + index in one flat file (dm_save_model)
+  void saveModel(const std::string &path) const { check(dm_save_model(h_, path.c_str())); }
+  void loadModel(const std::string &path) { check(dm_load_model(h_, path.c_str())); }
   // arithmetic of the beam-search scorer: DM_SCORER_AUTO (default), DM_SCORER_F32, DM_SCORER_SPLIT_F16 (dismember_hip.h)
   void setScorerMode(int mode) { check(dm_set_scorer_mode(h_, mode)); }
   int scorerModeInEffect() const {

@@ -79,6 +79,14 @@ int dm_level_start(int candidate_num, int *start_code, int *level);
 int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact,
                         int64_t n_elems);
 
+/* Checkpoint (replaces TDM.saveModel / loadModel, T/utils/Serialization.scala:60-101 — a Java ObjectOutputStream of the module graph
+ * there; tdm/src/test/scala/TdmModelTrainSpec.scala:85-96 pins save -> load -> identical recommendations): one flat little-endian
+ * file with the compact parameter vector in the loaded dtype plus the tree nodes and the item id -> leaf code map when they are
+ * loaded (layout: dismember_amd/csrc/checkpoint.hip.inc).  No optimizer state, like the reference.  dm_load_model replaces whatever
+ * tree / id maps / weights the handle holds with the file's. */
+int dm_save_model(dm_handle_t h, const char *path);
+int dm_load_model(dm_handle_t h, const char *path);
+
 /* Arithmetic of the beam-search scorer (dm_tdm_beam_search*, dm_otm_beam_search*; no reference counterpart: the
  * reference's Linear / MatMul call MKL sgemm, S/tensor/TensorNumeric.scala:265-266).
  *   DM_SCORER_F32        fp32-input MFMA for every product.
@@ -172,6 +180,13 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, const int32_t *item_node,
                          int64_t n_items, int L, int old_level, int level, int hierarchical, int min_level, int use_mask,
                          float *weights);
+/* The same with the catalogue's training rows (itemSequenceMap, built once per run: TreeLearning.scala:34-46) kept on the device
+ * across the gap steps of one JTM.optimize: dm_jtm_cache_rows uploads row_off [n_items+1] (row_off[0] == 0) / row_item_ids once
+ * (n_items == 0 drops the copy); dm_jtm_child_weights_cached scores the items [i_lo, i_lo + n_items) of that catalogue
+ * (item_node and weights are indexed from i_lo: a rank's item shard) and uploads nothing but item_node. */
+int dm_jtm_cache_rows(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, int64_t n_items, int L);
+int dm_jtm_child_weights_cached(dm_handle_t h, const int32_t *item_node, int64_t i_lo, int64_t n_items, int old_level, int level,
+                                int hierarchical, int min_level, int use_mask, float *weights);
 /* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable
  * descending), first choice, greedy capacity-bounded reBalance (:217-265).  old_node [n] =
  * tree.getAncestorAtLevel(item, level); out_node [n] = assigned child code (-1: dropped by the greedy loop).

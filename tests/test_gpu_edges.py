@@ -1,5 +1,7 @@
 """Edge cases and full-size properties (GPU): empty batches, history lengths 1..16, extreme beams, and — at BASELINE.json's
 config-2 / config-5 sizes, where the CPU oracle cannot follow — properties that do not depend on the size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -216,6 +218,34 @@ def test_jtm_rebalance_all_threads_equal_single_thread():
     eng.close()
 
 
+def test_jtm_rebalance_large_parent_equals_oracle(oracle):
+    """A parent with tens of thousands of items takes the selection path of the greedy re-balance (the max_assign-th element
+    of the total order (moved?, -weight, list position) + a sort of the overflow only) instead of the reference's full stable
+    sort: assignments must equal the oracle's reBalance (TreeLearning.scala:217-265) exactly — crowded ties (weights from 8
+    values), several rounds of overflow, items without rows."""
+    import ctypes as C
+    from dismember_amd import Engine
+    from dismember_amd import _native as N
+    rng = np.random.default_rng(18)
+    eng = Engine(0)
+    for n, gap, slack in ((60_000, 2, 1.01), (30_000, 3, 1.10), (5_000, 2, 1.0)):
+        old_level, level, node = 3, 3 + gap, 9
+        nchild = 1 << gap
+        w = (rng.integers(0, 8, (n, nchild)).astype(np.float32) - 3.0) / 2.0
+        w[:, 0] += 1.0                                                     # a popular child: several rounds of overflow
+        w[rng.random(n) < 0.02] = -1e6
+        first = (node << gap) + nchild - 1
+        old_node = (first + rng.integers(0, nchild, n)).astype(np.int32)
+        max_assign = int(np.ceil(n / nchild * slack))
+        out = np.empty(n, np.int32)
+        eng._chk(N.lib().dm_jtm_rebalance(eng._h, w.ctypes.data_as(N.f32p), old_node.ctypes.data_as(N.i32p), n, node, old_level, level,
+                                          max_assign, out.ctypes.data_as(N.i32p)))
+        ref = oracle.jtm_rebalance(np.arange(n, dtype=np.int32), w, old_node, node, old_level, level, max_assign)
+        ref = np.asarray(ref)
+        assert np.array_equal(out, ref), (n, gap, int((out != ref).sum()))
+    eng.close()
+
+
 def test_otm_device_resident_request_equals_host_path():
     """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
     from dismember_amd import Engine
@@ -309,3 +339,52 @@ def test_prune_order_with_mass_ties_and_signed_zeros(oracle, E):
         for beam, topk in ((200, 50), (37, 37), (256, 300)):
             replay_and_check(otree, odin, eng, seqs, beam, topk)
         eng.close()
+
+
+def test_checkpoint_save_load_identical_recommendations(tmp_path):
+    """tdm/src/test/scala/TdmModelTrainSpec.scala:85-96 (and OtmModelTrainSpec.scala:47-58): train a little, save, load into a
+    fresh engine: identical weights, identical recommendations — for the f32 TDM model (tree + id maps + weights) and for an
+    f64 OTM model (weights only)."""
+    from dismember_amd import Engine, TDM
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    t = np.load(os.path.join(g, "tdm_tree.npz")); w = np.load(os.path.join(g, "din_f32.npy"))
+    rng = np.random.default_rng(4)
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(w, 16, 8191)
+    eng.train_init(lr=1e-2)
+    codes = rng.integers(0, 8191, 200).astype(np.int32); seqs = rng.integers(0, 8191, (200, 10)).astype(np.int32)
+    eng.train_forward_backward(codes, seqs, None, (rng.random(200) < 0.5).astype(np.float32)); eng.adam_step()
+    q = np.array([0, 0, 2126, 204, 3257, 3439, 996, 1681, 3438, 1882], np.int32)
+    users = random_histories(rng, t["leaf_ids"], 32, 10)
+    m = TDM(eng, "din")
+    before1, before = m.recommend(q, 3, 20), eng.tdm_beam_search(users, 20, 10)
+    path = str(tmp_path / "tdm_model.ck")
+    m.save_model(path)
+    w_trained = eng.train_download("weights")
+    eng.close()
+    eng2 = Engine(0)
+    m2 = TDM.load_model(eng2, path, "din")
+    assert eng2.E == 16 and eng2.num_index == 8191 and eng2.dtype == np.float32
+    assert m2.recommend(q, 3, 20) == before1 and len(before1) == 3
+    after = eng2.tdm_beam_search(users, 20, 10)
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    eng2.train_init()
+    assert np.array_equal(eng2.train_download("weights"), w_trained)
+    eng2.close()
+    # f64 weights-only checkpoint (OTM)
+    w64 = np.load(os.path.join(g, "din_f64.npy"))
+    e3 = Engine(0); e3.load_weights_din(w64, 16, 8191)
+    codes_o = rng.integers(4095, 8191, (5, 10)).astype(np.int32)
+    b3 = e3.otm_beam_search_f64(codes_o, 20, 12)
+    p3 = str(tmp_path / "otm_model.ck")
+    e3.save_model(p3); e3.close()
+    e4 = Engine(0); e4.load_model(p3)
+    assert e4.dtype == np.float64
+    a3 = e4.otm_beam_search_f64(codes_o, 20, 12)
+    assert all(np.array_equal(a, b) for a, b in zip(b3, a3))
+    # a file that is not a checkpoint is refused
+    bad = str(tmp_path / "bad.ck"); open(bad, "wb").write(b"not a checkpoint")
+    with pytest.raises(Exception):
+        e4.load_model(bad)
+    e4.close()
