@@ -550,6 +550,7 @@ def main():
             ttgt = trng.choice(tree2["leaf_ids"], Tt).astype(np.int32)
             tr.step(tseq, ttgt)
             sync(); barrier()
+            tr.sync_s, tr.sync_calls = 0.0, 0
             t0 = time.perf_counter()
             nts = 5
             for _ in range(nts):
@@ -562,6 +563,12 @@ def main():
                      "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
                      "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world,
                      "gradient_exchange": ("dm_train_sync_gradients over dm_comm (%s)" % comm_transport) if comm is not None else "single worker"}
+            if comm is not None:
+                st = eng.train_sync_stats()
+                train["exchange"] = {"rccl_nranks": st["nranks"], "transport": st["transport"], "ms_per_step": tr.sync_s / max(tr.sync_calls, 1) * 1e3,
+                                     "touched_rows_this_rank": st["rows_mine"], "touched_rows_all_ranks": st["rows_total"],
+                                     "bytes_sent_per_step": st["bytes_sent"], "bytes_received_per_step": st["bytes_recv"],
+                                     "host_syncs_per_step": st["host_syncs"], "rows_per_s_per_rank": Tt * per * nts / dtt}
         elif comm_note:
             train = {"skipped": comm_note}
     # ---- extra: Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=1000, beam=50, 10M items.  The record is the fp64

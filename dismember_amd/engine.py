@@ -342,12 +342,12 @@ class Engine:
         self._chk(N.lib().dm_tdm_sample_train_batch_dev(self._h, None, None, T, L, _p(neg, N.i32p), neg.size, C.byref(o), None, None,
                                                         None, None, 0, C.byref(n)))
         R = max(n.value, 1)
-        need = T * L * 4 + T * 4 + R * 4 * (3 + L) + 1024
+        al = lambda v: (v + 255) & ~255
+        need = al(T * L * 4) + al(T * 4) + 2 * al(R * 4) + al(R * L * 4) + al(R * 4)     # the six sub-buffers as carved below
         if getattr(self, "_samp_bytes", 0) < need:
             if getattr(self, "_samp_buf", None):
                 self.dev_free(self._samp_buf)
             self._samp_buf, self._samp_bytes = self.dev_alloc(need + need // 2), need + need // 2
-        al = lambda v: (v + 255) & ~255
         base = self._samp_buf.value
         d_seq = C.c_void_p(base); base += al(T * L * 4)
         d_tgt = C.c_void_p(base); base += al(T * 4)
@@ -384,7 +384,12 @@ class Engine:
         """Var-size all-gather of DEVICE buffers over the attached communicator (dm_comm_all_gather_dev): uploads `arr`,
         gathers on the handle's stream (RCCL broadcasts, or host staging on the host transport), returns the concatenation."""
         a = np.ascontiguousarray(arr)
-        world = self._comm.world if hasattr(self._comm, "world") else 1
+        if hasattr(self._comm, "world"):
+            world = self._comm.world
+        else:                                          # a raw dm_comm_t (comm.make_clique): ask the library
+            r_, w_, t_ = C.c_int(0), C.c_int(1), C.c_int(0)
+            self._chk(N.lib().dm_comm_rank(self._comm, C.byref(r_), C.byref(w_), C.byref(t_)))
+            world = w_.value
         sizes = (C.c_uint64 * world)()
         d_send = self.dev_alloc(max(a.nbytes, 16))
         self.h2d(d_send, a)

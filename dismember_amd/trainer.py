@@ -19,9 +19,11 @@ class TDMTrainer:
     (dm_tdm_sample_train_batch_dev; rows never visit the host), "host" uses dm_tdm_make_train_batch."""
 
     def __init__(self, engine, neg_counts, start_level=1, use_mask=True, lr=1e-3, comm=None, seed=0, sampler="device",
-                 with_prob=False):
+                 with_prob=False, tolerance=20):
         self.e, self.neg, self.start, self.use_mask = engine, np.asarray(neg_counts, np.int32), start_level, use_mask
         self.comm, self.seed, self.it, self.sampler, self.with_prob = comm, seed, 0, sampler, bool(with_prob)
+        self.tolerance = int(tolerance)                   # model.sample_tolerance (NegativeSampler.scala:116-145)
+        self.sync_s, self.sync_calls = 0.0, 0             # wall time spent in the gradient exchange (bench.py reports it)
         engine.train_init(lr=lr)
         if comm is not None:
             engine.attach_comm(comm)
@@ -33,13 +35,16 @@ class TDMTrainer:
         seed = self.seed + 1000003 * self.it + rank
         if self.sampler == "device":
             loss = self.e.train_step_sampled(seq_item_ids, target_item_ids, self.neg, self.start, seed=seed,
-                                             use_mask=self.use_mask, with_prob=self.with_prob)
+                                             use_mask=self.use_mask, with_prob=self.with_prob, tolerance=self.tolerance)
         else:
             codes, seqs, mask, y = self.e.make_train_batch(seq_item_ids, target_item_ids, self.neg, self.start, seed=seed,
-                                                            use_mask=self.use_mask)
+                                                            use_mask=self.use_mask, with_prob=self.with_prob, tolerance=self.tolerance)
             loss = self.e.train_forward_backward(codes, seqs, self.e.rowmask_to_flat(mask, seqs.shape[1]), y)
         if self.comm is not None:
+            import time
+            t0 = time.perf_counter()
             self.e.train_sync_gradients()                 # syncGradients, LocalOptimizer.scala:164-187
+            self.sync_s += time.perf_counter() - t0; self.sync_calls += 1
         self.e.adam_step(1.0 / world)                     # ... / realParallelism, folded into the Adam kernel
         self.it += 1
         if self.comm is not None:

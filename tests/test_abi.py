@@ -97,3 +97,21 @@ def test_null_handle_is_an_error_not_a_crash():
         assert getattr(lib, name)(*args) == -1, name
         checked += 1
     assert checked >= 40
+
+
+def test_allreduce_grads_and_clique_argument_validation():
+    """dm_allreduce_grads / dm_comm_create_all (one process driving N GPUs) reject malformed calls before touching
+    a device: NULL list, n < 1, NULL entries, no devices, a device listed twice (RCCL takes one rank per device)."""
+    import ctypes as C
+    from dismember_amd import _native as N
+    lib = N.lib()
+    assert lib.dm_allreduce_grads(None, 1) == -1
+    hs = (C.c_void_p * 2)(None, None)
+    assert lib.dm_allreduce_grads(hs, 0) == -1
+    assert lib.dm_allreduce_grads(hs, 2) == -1                      # NULL handles inside the list
+    out = (C.c_void_p * 2)()
+    assert lib.dm_comm_create_all(0, (C.c_int * 1)(0), out) == -1
+    assert lib.dm_comm_create_all(2, None, out) == -1
+    assert lib.dm_comm_create_all(2, (C.c_int * 2)(0, 0), out) == -1
+    assert b"twice" in lib.dm_comm_last_error(None)
+    assert out[0] is None and out[1] is None

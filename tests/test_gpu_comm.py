@@ -142,3 +142,61 @@ def test_otm_trainer_replicas_stay_identical():
     assert out[0][1] == out[1][1] and len(out[0][1]) == 12 - 4 and all(np.isfinite(out[0][1]))       # the averaged per-level losses
     assert np.array_equal(out[0][2], out[1][2])
     assert not np.array_equal(out[0][2], np.load(os.path.join(GOLDEN, "din_f32.npy")))
+
+
+def _clique_train(devices):
+    """dm_comm_create_all + dm_allreduce_grads: ONE process drives every GPU of the list (the reference's one-JVM, N-worker shape)."""
+    import ctypes as C
+    from dismember_amd import Engine, _native as N
+    from dismember_amd.comm import make_clique
+    w = np.load(os.path.join(GOLDEN, "din_f32.npy"))
+    comms = make_clique(devices)
+    engs = []
+    for i, d in enumerate(devices):
+        e = Engine(d); e.load_weights_din(w, 16, 8191); e.train_init(lr=1e-3); e.attach_comm(comms[i]); engs.append(e)
+    local = []
+    for i, e in enumerate(engs):
+        codes, seqs, pad, y = _batch(i)
+        e.train_forward_backward(codes, seqs, pad, y)
+        local.append(e.train_download("grad"))
+    hs = (C.c_void_p * len(engs))(*[e._h for e in engs])
+    assert N.lib().dm_allreduce_grads(hs, len(engs)) == 0
+    summed = [e.train_download("grad") for e in engs]
+    st = engs[0].train_sync_stats()
+    for e in engs:
+        e.adam_step(1.0 / len(engs))
+    wts = [e.train_download("weights") for e in engs]
+    for e in engs:
+        e.close()
+    for c in comms:
+        N.lib().dm_comm_destroy(c)
+    return local, summed, wts, st
+
+
+def test_clique_single_device_is_a_no_op():
+    """n == 1: dm_comm_create_all gives a one-rank RCCL communicator and dm_allreduce_grads leaves the gradient untouched."""
+    local, summed, wts, st = _clique_train([0])
+    assert np.array_equal(local[0], summed[0]) and st["nranks"] == 1
+
+
+def test_clique_all_devices_replicas_identical():
+    """Every GPU of the box in one process (skipped on one-GPU boxes): the replicas' summed gradients and updated weights are
+    bit-identical, touched embedding rows equal the rank-ordered sum, the exchange needed two host synchronisations."""
+    from dismember_amd import _native as N
+    import ctypes as C
+    n = C.c_int(0)
+    N.lib().dm_device_count(C.byref(n))
+    if n.value < 2:
+        pytest.skip("needs >= 2 GPUs in one process (dm_comm_create_all); this box has %d" % n.value)
+    devs = list(range(min(n.value, 4)))
+    local, summed, wts, st = _clique_train(devs)
+    for r in range(1, len(devs)):
+        assert np.array_equal(summed[r], summed[0]) and np.array_equal(wts[r], wts[0])
+    NI, E = 8191, 16
+    ref = np.zeros_like(local[0][:NI * E])
+    for g in local:
+        ref = ref + g[:NI * E]                                  # rank order
+    assert np.array_equal(summed[0][:NI * E], ref)
+    dense = np.sum([g[NI * E:].astype(np.float64) for g in local], axis=0)
+    assert np.allclose(summed[0][NI * E:], dense, rtol=1e-5, atol=1e-7)
+    assert st["nranks"] == len(devs) and st["transport"] == "rccl" and st["host_syncs"] == 2

@@ -90,3 +90,14 @@ def test_scala_facades_call_existing_natives():
             assert len(_split_args(text[m.end():i - 1])) == methods[name], (f, name)
             calls += 1
     assert calls >= 20
+
+
+def test_integration_excerpts_match_sources():
+    """INTEGRATION.md shows the binding a maintainer adds; its code blocks are excerpts of the generated / hand-written sources
+    and must stay literal (a changed argument order in the generator must not leave a stale snippet in the document)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"<!-- excerpt: (\S+) -->\n```\w*\n(.*?)\n```", text, flags=re.S)
+    assert len(blocks) >= 4
+    for path, body in blocks:
+        src = open(os.path.join(ROOT, path)).read()
+        assert body in src, "INTEGRATION.md excerpt of %s is stale" % path
