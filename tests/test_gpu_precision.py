@@ -311,3 +311,56 @@ def test_full_size_properties_depth24(oracle):
         b = oracle.jtm_rebalance(jt.items[grp], w_gpu[grp], old_node[grp], int(node), old_level, level, 1)
         assert np.array_equal(a, b)
     eng.close()
+
+
+def test_full_size_otm_fp64_depth24():
+    """BASELINE configs[2] in the reference's own arithmetic at its own size: a DIN[Double] over the complete depth-24 tree
+    (33 554 431 x 128 doubles = 34.4 GB; with gradient and Adam state 137 GB on the device).  Size-independent properties of
+    the fused fp64 beam kernel (determinism, leaf range, distinct nodes, scores == the fp64 general forward on rows whose byte
+    offsets exceed 2^34), one LocalOptimizer iteration in fp64, and the f32 mirror following the trained weights."""
+    from dismember_amd import Engine, synth
+    from dismember_amd.otm_train import OTMTrainer
+    E, L, depth, beam, U = 128, 10, 24, 200, 96
+    NI = (1 << (depth + 1)) - 1
+    first = (1 << depth) - 1
+    eng = Engine(0)
+    eng.load_weights_din_synthetic_f64(E, NI, synth.SEED)
+    assert eng.scorer_mode()["mode"] == "f64"
+    rng = np.random.default_rng(9)
+    codes = (first + rng.integers(0, 1 << depth, size=(U, L))).astype(np.int32)
+    codes[rng.random((U, L)) < 0.15] = -1
+    codes[0] = -1
+    ids, sc, cnt = eng.otm_beam_search_f64(codes, beam, depth)
+    assert eng.last_beam_kernel().startswith("dm_beam64_kernel<128")
+    ids2, sc2, cnt2 = eng.otm_beam_search_f64(codes, beam, depth)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc, sc2) and np.array_equal(cnt, cnt2)
+    assert (cnt == 2 * beam).all() and (ids >= first).all() and (ids < NI).all()
+    assert all(len(set(r.tolist())) == 2 * beam for r in ids)
+    assert (ids.astype(np.int64) * E * 8 >= 1 << 34).all()
+    for u in (0, 1, U - 1):
+        pad = np.flatnonzero(np.tile(codes[u] < 0, 2 * beam)).astype(np.int32)
+        ref = eng.din_forward(ids[u], np.tile(codes[u], (2 * beam, 1)), pad, L=L)
+        assert ref.dtype == np.float64 and (np.abs(sc[u] - ref) <= 1e-10 + 1e-9 * np.abs(ref)).all(), u
+    # the per-level pipeline (the fallback for frontiers that outgrow LDS) agrees with the fused kernel
+    os.environ["DM_OTM64_PIPELINE"] = "1"
+    try:
+        idp, scp, cntp = eng.otm_beam_search_f64(codes[:8], beam, depth)
+    finally:
+        del os.environ["DM_OTM64_PIPELINE"]
+    assert np.array_equal(idp, ids[:8]) and (np.abs(scp - sc[:8]) <= 1e-10 + 1e-9 * np.abs(sc[:8])).all()
+    # one training iteration in fp64 (17 levels at beam 200 would be 8 000 rows per level with 20 users; 6 users at beam 20 here)
+    otr = OTMTrainer(eng, depth, 20, seq_len=L, lr=1e-3)
+    targets = [(first + rng.integers(0, 1 << depth, size=2)).tolist() for _ in range(6)]
+    l1 = otr.train_batch(codes[1:7], targets)
+    l2 = otr.train_batch(codes[1:7], targets)
+    assert len(l1) == depth - 4 and np.isfinite(l1).all() and np.isfinite(l2).all() and sum(l2) < sum(l1)
+    # the fp64 search sees the trained weights; the throughput mode (f32 mirror, rebuilt lazily) stays within the f32 tolerance of it
+    ida, sca, _ = eng.otm_beam_search_f64(codes[1:3], beam, depth)
+    pad = np.flatnonzero(np.tile(codes[1] < 0, 2 * beam)).astype(np.int32)
+    ref = eng.din_forward(ida[0], np.tile(codes[1], (2 * beam, 1)), pad, L=L)
+    assert (np.abs(sca[0] - ref) <= 1e-10 + 1e-9 * np.abs(ref)).all()
+    eng.set_scorer_mode("f32")
+    idf, scf, _ = eng.otm_beam_search(codes[1:3], beam, depth)
+    ref32 = eng.din_forward(idf[0], np.tile(codes[1], (2 * beam, 1)), pad, L=L)
+    assert (np.abs(scf[0] - ref32) <= ATOL + RTOL * np.abs(ref32)).all()
+    eng.close()
