@@ -91,6 +91,9 @@ struct dm_ctx {
   size_t ev_used = 0;
   std::vector<int> ev_kind;    // per pair: 0 = a main kernel, 1 = the second pass over the users the one-wave kernel deferred
   int ev_next_kind = 0;
+  bool ev_skip = false;        // the single-request path launches without its event pair ...
+  bool time_direct = false;    // ... unless DM_TIME_DIRECT=1 asks for kernel timings of that path too (probes)
+  bool direct_ok = true;       // host-mapped single-request path enabled (DM_NO_DIRECT=1 turns it off)
   char last_kernel[64] = "";   // the search kernel of the last beam search (measurement: dm_last_beam_kernel)
   unsigned long long *d_rows = nullptr;
   unsigned long long *d_phase = nullptr;   // 8 debug counters
@@ -294,6 +297,8 @@ int dm_create(int device_id, dm_handle_t *out) {
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipGetDeviceProperties failed"); }
   h->n_cu = prop.multiProcessorCount;
   { const char *e_ = getenv("DM_BEAM_W"); if (e_) h->beam_w = e_[0] == '1'; }
+  { const char *e_ = getenv("DM_NO_DIRECT"); if (e_ && e_[0] == '1') h->direct_ok = false; }
+  { const char *e_ = getenv("DM_TIME_DIRECT"); if (e_ && e_[0] == '1') h->time_direct = true; }
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipStreamCreate failed"); }
   if (hipMalloc((void **)&h->d_rows, 64) != hipSuccess) { delete h; return fail(nullptr, DM_ERR_HIP, "hipMalloc failed"); }
   (void)hipMemset(h->d_rows, 0, 64);
@@ -777,8 +782,11 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
     BeamWLds l = dm_beamw_lds(h->embed, cap, pcap, kq);
     if (l.total <= 160 * 1024) { nteams = DMW_NWAVES; pl->lds = l.total; pl->wkernel = true; }
   }
+  // LDS-fed kernel: teams of 8 / nteams waves.  A frontier of at most 256 slots fits ONE wave's register sort, so small beams
+  // (the reference's serving default is candidateNum 20) run as eight one-wave teams: no team barriers at all on the latency
+  // chain sort -> expand -> gather -> score of a level, and eight users per CU in flight instead of four
   if (!nteams)
-  for (int cand = 4; cand >= 1; cand >>= 1) {
+  for (int cand = (pcap <= 256 ? 8 : 4); cand >= 1; cand >>= 1) {
     BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, use_split(h));
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
@@ -815,9 +823,16 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
 }
 
 template <int E, int KQ, bool SPLIT>
-static int launch_beam_EK(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+static int launch_beam_EK(dm_ctx *h, const BeamParams &p_in, const SearchPlan &pl) {
+  BeamParams p = p_in;
+  p.static_users = (p.mode != 2 && !p.user_list && p.U <= (int64_t)pl.grid * pl.nteams) ? 1 : 0;
   HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
   if (h->ev_next_kind == 0) snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_kernel<%d, %d, %s>", E, KQ, SPLIT ? "true" : "false");
+  if (h->ev_skip && !h->time_direct) {       // single-request path: the launch and nothing else
+    hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    return DM_OK;
+  }
   hipEvent_t e0, e1;
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
@@ -1074,7 +1089,7 @@ static void fill_common(dm_ctx *h, BeamParams &p) {
 
 static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, const dm_tdm_search_opts *o, int max_beam,
                           const int64_t *d_coff, const int32_t *d_cids, int32_t *d_ids, float *d_scores, int32_t *d_counts,
-                          int trace_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn) {
+                          int trace_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn, bool *direct = nullptr) {
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "tdm beam search: tree, id maps and weights must be loaded first");
   if (U < 0 || L <= 0 || L > DM_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..16)");
   if (U == 0) return DM_OK;          // an empty batch is not an error
@@ -1099,6 +1114,20 @@ static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, con
   p.ws_code = (int32_t *)h->d_ws; p.ws_score = (float *)h->d_ws + per; p.ws_khi = (uint32_t *)h->d_ws + 2 * per;
   p.ws_klo = (uint32_t *)h->d_ws + 3 * per; p.ws_cap = pl.ws_cap;
   p.trace_codes = d_tc; p.trace_scores = d_ts; p.trace_counts = d_tn; p.trace_levels = trace_levels;
+  if (direct) {
+    // single-request path (tdm_search_host): request and results live in host-mapped pinned memory, one team per user without the
+    // work queue, the kernel fills every output slot and publishes the counts last — ONE launch, no memsets, no copies, no events
+    *direct = *direct && !pl.wkernel && U <= (int64_t)pl.grid * pl.nteams && !d_coff && !d_tn;
+    if (!*direct) return DM_OK;             // nothing launched: the caller takes the staged path
+    {
+      p.host_direct = 1;
+      p.scored_rows = h->d_rows + 3;          // not zeroed on this path: keep dm_last_scored_rows' counter out of it
+      h->ev_skip = true;
+      const int rc_ = launch_beam(h, p, pl);
+      h->ev_skip = false;
+      return rc_;
+    }
+  }
   HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
   HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
@@ -1171,10 +1200,42 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
     if (staged && h->stage_bytes < b_seq + down) {
       if (h->h_stage) (void)hipHostFree(h->h_stage);
       h->h_stage = nullptr; h->stage_bytes = 0;
-      if (hipHostMalloc((void **)&h->h_stage, 256u << 10, hipHostMallocDefault) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "hipHostMalloc failed"); break; }
+      if (hipHostMalloc((void **)&h->h_stage, 256u << 10, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "hipHostMalloc failed"); break; }
       h->stage_bytes = 256u << 10;
     }
     if (staged) memcpy(h->h_stage, seq, (size_t)U * L * 4);
+    if (staged && h->direct_ok && U <= 8) {
+      // Single-request path (the reference's serving loop: one user per call, examples/.../tdm/package.scala:114-124).  The staging
+      // block is host-mapped: the kernel reads the request from it and writes the results into it; the host polls the counts.
+      int32_t *m_ids = (int32_t *)(h->h_stage + b_seq);
+      float *m_sc = (float *)(h->h_stage + b_seq + b_out);
+      volatile int32_t *m_cnt = (volatile int32_t *)(h->h_stage + b_seq + 2 * b_out);
+      for (int64_t u = 0; u < U; u++) m_cnt[u] = -1;
+      bool direct = true;
+      rc = tdm_search_dev(h, (const int32_t *)h->h_stage, U, L, opts, mb, nullptr, nullptr, m_ids, m_sc, (int32_t *)m_cnt, 0, nullptr, nullptr,
+                          nullptr, &direct);
+      if (rc != DM_OK) break;
+      if (direct) {
+        bool done = false;
+        for (long spin = 0; !done; spin++) {
+          done = true;
+          for (int64_t u = 0; u < U; u++) done = done && m_cnt[u] >= 0;
+          if (!done && (spin & 0xFFF) == 0xFFF && hipStreamQuery(h->stream) != hipErrorNotReady) {
+            // the stream is idle (or failed) and the flags never came: a kernel fault
+            hipError_t e = hipStreamSynchronize(h->stream);
+            done = true;
+            for (int64_t u = 0; u < U; u++) done = done && m_cnt[u] >= 0;
+            if (!done) { rc = fail(h, DM_ERR_HIP, std::string("tdm beam search (single-request path): ") + (e != hipSuccess ? hipGetErrorString(e) : "kernel finished without results")); break; }
+          }
+        }
+        if (rc != DM_OK) break;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        memcpy(out_ids, m_ids, nout * 4); memcpy(out_scores, m_sc, nout * 4);
+        for (int64_t u = 0; u < U; u++) out_counts[u] = m_cnt[u];
+        break;
+      }
+      // the plan did not allow it (one-wave-per-SIMD kernel, too many users for the grid): fall through to the staged path
+    }
     if (hipMemcpyAsync(d_seq, staged ? (const void *)h->h_stage : (const void *)seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
     if (coff) {
       d_coff = (int64_t *)base; base += b_coff;

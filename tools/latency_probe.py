@@ -23,6 +23,14 @@ t0 = time.perf_counter()
 for _ in range(20):
     tdm.recommend(qb, 10, 20)
 print("256 users per call: %.1f us per call" % ((time.perf_counter() - t0) / 20 * 1e6))
+eng.close()
+os.environ["DM_TIME_DIRECT"] = "1"          # the single-request path launches without its event pair unless asked
+eng = Engine(0)
+eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+eng.load_weights_din(w, 16, 8191)
+tdm = TDM(eng, "din")
+for _ in range(10):
+    tdm.recommend(q, 10, 20)
 eng.timing_reset()
 for _ in range(100):
     tdm.recommend(q, 10, 20)
