@@ -71,6 +71,7 @@ struct dm_ctx {
   // fp64 beam kernel (beam_kernel_f64.hip.inc): A / B fragments of att.W, W1a, W1b; per-team K / G fragment scratch
   void *d_frag64 = nullptr, *d_scratch64 = nullptr;
   bool frag64_dirty = true;
+  double b2_64 = 0.0;            // l2.b of the f64 model (read back when the fragments are built)
   size_t scratch64_bytes = 0;
   // training state (dm_train_init)
   bool train_ready = false;
@@ -1344,8 +1345,6 @@ int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U,
   if (!d_seq_codes || !d_out_node_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (use_f64_beam(h)) {
-    HIPCHK(h, hipMemsetAsync(d_out_node_ids, 0xFF, (size_t)U * 2 * beam * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(d_out_scores, 0, (size_t)U * 2 * beam * 4, h->stream));
     return otm64_search_dev(h, d_seq_codes, U, L, beam, leaf_level, d_out_node_ids, nullptr, d_out_scores, d_out_counts, 0, 0, nullptr,
                             nullptr, nullptr, nullptr);
   }

@@ -36,3 +36,21 @@ for _ in range(100):
     tdm.recommend(q, 10, 20)
 n, ms = eng.timing_get()
 print("kernel time inside the single-user call: %.1f us (HIP events, %d launches)" % (ms / n * 1e3, n))
+# ---- OTM.recommend on the bundled DIN[Double] (examples/.../otm/package.scala:101-105)
+from dismember_amd import OTM
+eng.close()
+w6 = np.load(os.path.join(g, "din_f64.npy")); om = np.load(os.path.join(g, "otm_mapping.npy"))
+e2 = Engine(0); e2.load_weights_din(w6, 16, 8191)
+mo = OTM(e2, {int(a_): int(b_) for a_, b_ in om})
+qo = [int(x) for x in om[:10, 0]]
+for _ in range(10):
+    mo.recommend(qo, 10, 20)
+t0 = time.perf_counter()
+for _ in range(100):
+    mo.recommend(qo, 10, 20)
+print("OTM.recommend (1 user, topk 10, beam 20, fp64): %.1f us per call (%s)" % ((time.perf_counter() - t0) / 100 * 1e6, e2.last_beam_kernel()))
+e2.timing_reset()
+for _ in range(100):
+    mo.recommend(qo, 10, 20)
+n, ms = e2.timing_get()
+print("kernel time inside the OTM call: %.1f us (%d launches)" % (ms / max(n, 1) * 1e3, n))
