@@ -49,6 +49,7 @@ struct dm_ctx {
   // weights
   bool w_loaded = false;
   int dtype = DM_F32, embed = 0;
+  int embed_log = 0;           // the MODEL's embed size; embed is the kernels' (16 / 32 / 64 / 128): other sizes are zero-padded at load
   int64_t num_index = 0;
   void *d_compact = nullptr;   // as loaded (float or double)
   float *d_emb32 = nullptr;    // f32 table (aliases d_compact for DM_F32)
@@ -174,6 +175,7 @@ struct DinFwdParams {
   const int32_t *codes, *seqs;
   const unsigned *rowmask;
   T *out;
+  T sm_scale;                  // 1 / sqrt(embedSize) of the model (the table may be zero-padded to E)
 };
 
 template <typename T>
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void dm_din_forward_kernel(DinFwdParams<T> p) 
   const int E = p.E, L = p.L;
   T *q = (T *)smem_fw + (size_t)wave * (3 * E + 32);
   T *comb = q + E, *att = comb + E, *sc = att + E;
-  const T scale = (T)(1.0 / sqrt((double)E));
+  const T scale = p.sm_scale;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.B; row += (int64_t)gridDim.x * 4) {
     const int32_t code = p.codes[row];
     for (int e = lane; e < E; e += 64) q[e] = code >= 0 ? p.emb[(int64_t)code * E + e] : (T)0;
@@ -255,6 +257,10 @@ static int dm_alloc(dm_ctx *h, void **p, size_t bytes) {
     if (rc_ != DM_OK) return rc_;                              \
   } while (0)
 static void dm_free_ptr(void *p) { if (p) (void)hipFree(p); }
+
+// Mask.scala:10 — scale = 1 / sqrt(embedSize) of the model as loaded (zero padding of the table does not change it)
+static double sm_scale64(const dm_ctx *h) { return 1.0 / sqrt((double)(h->embed_log > 0 ? h->embed_log : h->embed)); }
+static float sm_scale32(const dm_ctx *h) { return (float)sm_scale64(h); }
 
 static int level_start_int(int candidate_num, int *start, int *level) {
   if (candidate_num <= 0) return DM_ERR_INVALID;
@@ -499,6 +505,44 @@ static int upload_derived(dm_ctx *h, int E, const T *att_w) {
   return DM_OK;
 }
 
+// Embedding sizes the kernels are built for; any other size up to 128 is zero-padded to the next one at load (S/nn/Attention.scala,
+// T/model/DIN.scala take any embedSize).  Zero columns / rows change no product: q.k, att.W k, W1 [q ; att] and w2 . h keep their
+// values, the padded hidden units are relu(0) = 0, and training leaves the padding at zero (its gradients are products with zero
+// inputs; Adam moves a parameter whose gradient history is zero by 0 / (0 + eps)).  Only the softmax scale 1 / sqrt(embedSize)
+// (Mask.scala:10) must stay the model's: sm_scale64().
+static int native_embed(int E) { return E <= 0 ? 0 : E <= 16 ? 16 : E <= 32 ? 32 : E <= 64 ? 64 : E <= 128 ? 128 : 0; }
+static int64_t compact_len_for(int64_t num_index, int64_t E) { return num_index * E + 3 * E * E + 2 * E + 1; }
+
+template <typename T>
+static void pad_compact(const T *src, int E, int Ep, int64_t NI, T *dst) {       // dst: compact_len_for(NI, Ep) elements, zeroed here
+  memset(dst, 0, (size_t)compact_len_for(NI, Ep) * sizeof(T));
+  for (int64_t r = 0; r < NI; r++) memcpy(dst + r * Ep, src + r * E, (size_t)E * sizeof(T));
+  const T *s_att = src + NI * E, *s_l1 = s_att + (int64_t)E * E, *s_b1 = s_l1 + (int64_t)E * 2 * E, *s_w2 = s_b1 + E;
+  T *d_att = dst + NI * Ep, *d_l1 = d_att + (int64_t)Ep * Ep, *d_b1 = d_l1 + (int64_t)Ep * 2 * Ep, *d_w2 = d_b1 + Ep;
+  for (int o = 0; o < E; o++) {
+    memcpy(d_att + (int64_t)o * Ep, s_att + (int64_t)o * E, (size_t)E * sizeof(T));
+    memcpy(d_l1 + (int64_t)o * 2 * Ep, s_l1 + (int64_t)o * 2 * E, (size_t)E * sizeof(T));                  // W1a half
+    memcpy(d_l1 + (int64_t)o * 2 * Ep + Ep, s_l1 + (int64_t)o * 2 * E + E, (size_t)E * sizeof(T));        // W1b half
+  }
+  memcpy(d_b1, s_b1, (size_t)E * sizeof(T));
+  memcpy(d_w2, s_w2, (size_t)E * sizeof(T));
+  d_w2[Ep] = s_w2[E];
+}
+template <typename T>
+static void unpad_compact(const T *src, int E, int Ep, int64_t NI, T *dst) {     // src padded, dst: compact_len_for(NI, E) elements
+  for (int64_t r = 0; r < NI; r++) memcpy(dst + r * E, src + r * Ep, (size_t)E * sizeof(T));
+  const T *s_att = src + NI * Ep, *s_l1 = s_att + (int64_t)Ep * Ep, *s_b1 = s_l1 + (int64_t)Ep * 2 * Ep, *s_w2 = s_b1 + Ep;
+  T *d_att = dst + NI * E, *d_l1 = d_att + (int64_t)E * E, *d_b1 = d_l1 + (int64_t)E * 2 * E, *d_w2 = d_b1 + E;
+  for (int o = 0; o < E; o++) {
+    memcpy(d_att + (int64_t)o * E, s_att + (int64_t)o * Ep, (size_t)E * sizeof(T));
+    memcpy(d_l1 + (int64_t)o * 2 * E, s_l1 + (int64_t)o * 2 * Ep, (size_t)E * sizeof(T));
+    memcpy(d_l1 + (int64_t)o * 2 * E + E, s_l1 + (int64_t)o * 2 * Ep + Ep, (size_t)E * sizeof(T));
+  }
+  memcpy(d_b1, s_b1, (size_t)E * sizeof(T));
+  memcpy(d_w2, s_w2, (size_t)E * sizeof(T));
+  d_w2[E] = s_w2[Ep];
+}
+
 template <typename T>
 static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64_t n_elems) {
   const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
@@ -518,20 +562,31 @@ static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64
   int rc = upload_derived<T>(h, E, w + num_index * E);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
   return DM_OK;
+}
+template <typename T>
+static int load_weights_any_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64_t n_elems) {
+  const int Ep = native_embed(E);
+  if (Ep == E) return load_weights_t<T>(h, E, num_index, w, n_elems);
+  if (n_elems != compact_len_for(num_index, E)) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: n_elems does not match the DIN layout for (E, num_index)");
+  std::vector<T> padded((size_t)compact_len_for(num_index, Ep));
+  pad_compact<T>(w, E, Ep, num_index, padded.data());
+  const int rc = load_weights_t<T>(h, Ep, num_index, padded.data(), (int64_t)padded.size());
+  if (rc == DM_OK) h->embed_log = E;
+  return rc;
 }
 
 int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact, int64_t n_elems) {
   if (!h) return DM_ERR_INVALID;
   if (!compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: bad arguments");
-  if (E != 16 && E != 32 && E != 64 && E != 128)
-    return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 16, 32, 64 or 128");
+  if (E < 1 || E > 128)
+    return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 1 .. 128 (sizes other than 16 / 32 / 64 / 128 are zero-padded to the next of them)");
   if (dtype != DM_F32 && dtype != DM_F64) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: dtype");
   HIPCHK(h, hipSetDevice(h->device));
   h->dtype = dtype;
-  return dtype == DM_F32 ? load_weights_t<float>(h, E, num_index, (const float *)compact, n_elems)
-                         : load_weights_t<double>(h, E, num_index, (const double *)compact, n_elems);
+  return dtype == DM_F32 ? load_weights_any_t<float>(h, E, num_index, (const float *)compact, n_elems)
+                         : load_weights_any_t<double>(h, E, num_index, (const double *)compact, n_elems);
 }
 
 int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_compact, int64_t n_elems) {
@@ -549,7 +604,7 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
   HIPCHK(h, hipMemcpy(t.data(), d_compact + num_index * E, (size_t)tail * 4, hipMemcpyDeviceToHost));
   int rc = upload_derived<float>(h, E, t.data());
   if (rc != DM_OK) return rc;
-  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
   return DM_OK;
 }
 
@@ -575,7 +630,7 @@ int dm_load_weights_din_dev_f64(dm_handle_t h, int E, int64_t num_index, double 
   int rc = upload_derived<double>(h, E, t.data());
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->embed = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
   return DM_OK;
 }
 
@@ -667,6 +722,7 @@ static int din_forward_t(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seq
   T b2;
   HIPCHK(h, hipMemcpy(&b2, l1_b + 2 * E, sizeof(T), hipMemcpyDeviceToHost));
   p.b2 = b2; p.E = E; p.L = L; p.B = B; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.out = d_out;
+  p.sm_scale = (T)sm_scale64(h);
   int64_t blocks = (B + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   size_t lds = (size_t)4 * (3 * E + 32) * sizeof(T);
@@ -694,7 +750,7 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
   RowsParams p;
   p.emb = h->d_emb32; p.attA = h->d_attA; p.w1aA = h->d_w1aA; p.w1bA = h->d_w1bA; p.b1 = h->d_b1; p.w2 = h->d_w2;
   p.b2 = h->b2; p.num_index = h->num_index; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.B = B; p.L = L;
-  p.out = d_out;
+  p.out = d_out; p.sm_scale = sm_scale32(h);
   switch (h->embed) {
     case 16: return launch_rows_E<16>(h, p);
     case 32: return launch_rows_E<32>(h, p);
@@ -1084,6 +1140,7 @@ static void fill_common(dm_ctx *h, BeamParams &p) {
   p.exists_bits = h->d_exists; p.leaf_bits = h->d_leaf; p.node_id = h->d_node_id; p.id_to_code = h->d_id_to_code;
   p.n_slots = h->n_slots; p.non_leaf_offset = h->non_leaf_offset; p.max_code = h->max_code; p.max_level = h->max_level;
   p.scored_rows = h->d_rows;
+  p.sm_scale = sm_scale32(h);
   p.phase_cycles = h->d_phase;
   p.next_user = h->d_rows + 1;
 }

@@ -75,7 +75,10 @@ int dm_level_start(int candidate_num, int *start_code, int *level);
 /* compact parameter vector in Graph.parameters order (S/nn/graphnn/Graph.scala:37-48,
  * S/nn/mixin/Module.scala:9-45; DIN: T/model/DIN.scala:18-42):
  *   [emb num_index x E ; att.W E x E ; l1.W E x 2E ; l1.b E ; l2.W 1 x E ; l2.b 1]
- * E must be a multiple of 16 (16..128). */
+ * E: any size 1..128 (the reference's embedSize is free).  The kernels are built for 16 / 32 / 64 / 128; other sizes are zero-padded to
+ * the next of them on the device (same function: zero columns change no product, the softmax scale stays 1 / sqrt(E)); every vector
+ * that crosses the boundary (this one, dm_train_download, the checkpoint) keeps the MODEL's layout.  dm_load_weights_din_dev* and the
+ * raw device-pointer exchange (dm_train_dense_block / _export_rows / _add_rows) take native sizes only. */
 int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact,
                         int64_t n_elems);
 

@@ -388,3 +388,65 @@ def test_checkpoint_save_load_identical_recommendations(tmp_path):
     with pytest.raises(Exception):
         e4.load_model(bad)
     e4.close()
+
+
+@pytest.mark.parametrize("E,dtype", [(24, np.float32), (48, np.float32), (100, np.float32), (80, np.float64), (8, np.float64)])
+def test_embed_sizes_the_kernels_pad(oracle, tmp_path, E, dtype):
+    """The reference takes any embedSize (S/nn/Attention.scala:34-53, T/model/DIN.scala:18-42); the kernels are built for 16 / 32 /
+    64 / 128 and every other size up to 128 is zero-padded on the device, with the softmax scale 1 / sqrt(embedSize) kept the
+    model's.  Forward, beam search (trace replay), one training step + Adam and the checkpoint see the MODEL's own layout."""
+    from dismember_amd import Engine
+    from test_gpu_parity import replay_and_check
+    rng = np.random.default_rng(E)
+    f64 = dtype == np.float64
+    depth, items, L = 7, 100, 10
+    NI = (1 << (depth + 1)) - 1
+    t = synthetic_tree(rng, depth, items)
+    w = random_din_weights(rng, E, NI, dtype=dtype, std=0.2, bias_std=0.2)
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], depth); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(w, E, NI)
+    odin = oracle.Din(w.copy(), E, L, NI)
+    B = 200
+    codes = rng.integers(0, NI, B).astype(np.int32); seqs = rng.integers(0, NI, (B, L)).astype(np.int32)
+    seqs[rng.random((B, L)) < 0.2] = -1
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    ref = odin.forward(codes, seqs, pad)
+    got = eng.din_forward(codes, seqs, pad)
+    tol = (1e-10, 1e-9) if f64 else (1e-5, 1e-4)
+    assert got.dtype == dtype and (np.abs(got - ref) <= tol[0] + tol[1] * np.abs(ref)).all()
+    if not f64:
+        otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], depth)
+        replay_and_check(otree, odin, eng, random_histories(rng, t["leaf_ids"], 6, L), 12, 8)
+    else:
+        oc = rng.integers((1 << depth) - 1, NI, (4, L)).astype(np.int32); oc[0, :3] = -1
+        ids, sc, cnt = eng.otm_beam_search_f64(oc, 12, depth)
+        for u in range(4):
+            oi, osc = oracle.otm_beam_search(odin, oc[u], depth, 12)
+            assert np.array_equal(ids[u, :cnt[u]], oi) and (np.abs(sc[u, :cnt[u]] - osc) <= 1e-10 + 1e-9 * np.abs(osc)).all()
+    # training: gradient and Adam in the model's layout
+    eng.train_init(lr=1e-3)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    loss = eng.train_forward_backward(codes, seqs, pad, y)
+    oloss, og = odin.train_grads(codes, seqs, pad, y)
+    g = eng.train_download("grad")
+    assert g.shape == w.shape and abs(loss - oloss) <= (1e-10 + 1e-9 * abs(oloss) if f64 else 1e-5 + 1e-4 * abs(oloss))
+    gt = (1e-10, 1e-9) if f64 else (2e-5, 1e-4)
+    assert (np.abs(g - og) <= gt[0] * np.abs(og).max() + gt[1] * np.abs(og)).all()
+    eng.adam_step()
+    w1 = eng.train_download("weights")
+    refw = w.copy(); opt = oracle.Adam(refw.size, dtype, lr=1e-3); opt.step(refw, g.copy())
+    assert np.array_equal(w1, refw)
+    path = str(tmp_path / "m.ck")
+    eng.save_model(path); eng.close()
+    e2 = Engine(0); e2.load_model(path)
+    assert e2.E == E and np.array_equal(e2.din_forward(codes, seqs, pad), Engine_forward_after(w1, E, NI, codes, seqs, pad, dtype))
+    e2.close()
+
+
+def Engine_forward_after(w, E, NI, codes, seqs, pad, dtype):
+    from dismember_amd import Engine
+    e = Engine(0); e.load_weights_din(w.astype(dtype), E, NI)
+    out = e.din_forward(codes, seqs, pad)
+    e.close()
+    return out
