@@ -64,6 +64,8 @@ struct dm_ctx {
   bool beam_w = true;          // split scorer on the one-wave-per-SIMD kernel (beam_kernel_w.hip.inc); DM_BEAM_W=0 in the environment selects the LDS-fed kernel
   bool split_dirty = true;
   void *d_wsplit = nullptr;
+  void *d_rows_split = nullptr;   // general-rows split kernel: fp16 hi / lo planes of W1a and M = W1b att.W, then M in fp32
+  int sh_r = 0; bool rows_split_dirty = true;
   void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)
   size_t emb_split_bytes = 0;
   unsigned *d_maxabs = nullptr;
@@ -325,6 +327,7 @@ static void free_weights(dm_ctx *h) {
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
   dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
+  dm_free_ptr(h->d_rows_split); h->d_rows_split = nullptr; h->rows_split_dirty = true;
   dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
   dm_free_ptr(h->d_frag64); h->d_frag64 = nullptr; h->frag64_dirty = true;
   dm_free_ptr(h->d_tr64); h->d_tr64 = nullptr; dm_free_ptr(h->d_tail32); h->d_tail32 = nullptr; h->f32_mirror_dirty = false;
@@ -744,9 +747,62 @@ static int launch_rows_E(dm_ctx *h, const RowsParams &p) {
   return DM_OK;
 }
 
+static bool use_split(const dm_ctx *h);
+static int ensure_split(dm_ctx *h);
+static int split_shift(unsigned maxbits);
+// fp16 planes of the general-rows split kernel (rows_kernel.hip.inc): follow the weights like the beam kernels' planes
+static int ensure_rows_split(dm_ctx *h) {
+  int rc = ensure_split(h);        // sh_e = the table's scale (one pass over the table per weight change, shared with the beam kernels)
+  if (rc != DM_OK) return rc;
+  if (!h->rows_split_dirty && h->d_rows_split) return DM_OK;
+  const int E = h->embed;
+  const size_t plane_bytes = (size_t)4 * E * E * 2;
+  if (!h->d_rows_split) ALLOC(h, h->d_rows_split, plane_bytes + (size_t)E * E * 4);
+  float *Mbuf = (float *)((char *)h->d_rows_split + plane_bytes);
+  HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, 8, h->stream));
+  hipLaunchKernelGGL(dm_rows_m_kernel, dim3(64), dim3(256), 0, h->stream, h->d_attA, h->d_w1aA, h->d_w1bA, E, Mbuf, h->d_maxabs);
+  HIPCHK(h, hipGetLastError());
+  unsigned mb[2];
+  HIPCHK(h, hipMemcpyAsync(mb, h->d_maxabs, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->sh_r = split_shift(mb[0] > mb[1] ? mb[0] : mb[1]);
+  hipLaunchKernelGGL(dm_build_rows_planes_kernel, dim3(64), dim3(256), 0, h->stream, h->d_w1aA, (const float *)Mbuf, E, ldexpf(1.0f, h->sh_r),
+                     (_Float16 *)h->d_rows_split);
+  HIPCHK(h, hipGetLastError());
+  h->rows_split_dirty = false;
+  return DM_OK;
+}
+
+template <int E>
+static int launch_rows_split_E(dm_ctx *h, const RowsSplitParams &p) {
+  const int lds = 4 * E * E * 2;
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_din_rows_split_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int64_t tiles = (p.B + 15) / 16;
+  int64_t blocks = (tiles + DM_NWAVES - 1) / DM_NWAVES;
+  if (blocks > h->n_cu) blocks = h->n_cu;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dm_din_rows_split_kernel<E>, dim3((unsigned)blocks), dim3(DM_BLOCK), lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  return DM_OK;
+}
+
 // f32 general-rows forward on device buffers (asynchronous on the handle's stream)
 static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
                         int L, float *d_out) {
+  if (use_split(h)) {      // the default arithmetic for E = 32 / 64 / 128 (DM_SCORER_F32 keeps the fp32-input kernel below)
+    int rc = ensure_rows_split(h);
+    if (rc != DM_OK) return rc;
+    RowsSplitParams q;
+    q.emb = h->d_emb32; q.planes = (const dm_h8 *)h->d_rows_split; q.b1 = h->d_b1; q.w2 = h->d_w2; q.b2 = h->b2;
+    q.emb_scale = ldexpf(1.0f, h->sh_e); q.out_unscale = ldexpf(1.0f, -(h->sh_e + h->sh_r));
+    q.num_index = h->num_index; q.codes = d_codes; q.seqs = d_seqs; q.rowmask = d_rowmask; q.B = B; q.L = L; q.out = d_out;
+    q.sm_scale = sm_scale32(h);
+    switch (h->embed) {
+      case 32: return launch_rows_split_E<32>(h, q);
+      case 64: return launch_rows_split_E<64>(h, q);
+      case 128: return launch_rows_split_E<128>(h, q);
+    }
+  }
   RowsParams p;
   p.emb = h->d_emb32; p.attA = h->d_attA; p.w1aA = h->d_w1aA; p.w1bA = h->d_w1bA; p.b1 = h->d_b1; p.w2 = h->d_w2;
   p.b2 = h->b2; p.num_index = h->num_index; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.B = B; p.L = L;
@@ -1026,6 +1082,7 @@ static int ensure_split(dm_ctx *h) {
     HIPCHK(h, hipGetLastError());
   }
   h->split_dirty = false;
+  h->rows_split_dirty = true;
   return DM_OK;
 }
 

@@ -108,6 +108,53 @@ def test_split_scorer_error_vs_exact(oracle, E, case):
     assert rs <= ro * 1.05 and rf <= ro * 1.05, line                # and neither worse than the fp32 oracle's own rounding
 
 
+@pytest.mark.parametrize("E,case", [(128, "plain"), (64, "plain"), (32, "plain"), (128, "wide_range"), (128, "big_bias")])
+def test_rows_split_kernel_error_vs_exact(oracle, E, case):
+    """The general-rows forward (dm_din_forward, JTM scoring) in the split-fp16 arithmetic — W1a q + (W1b att.W) c on
+    v_mfma_f32_16x16x32_f16, rows_kernel.hip.inc — against the exact (fp64) value of the SAME fp32 weights: no less accurate than
+    the fp32-input MFMA kernel within 25 %, neither worse than the fp32 CPU oracle's own rounding, both inside the stated tolerance."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(7000 + E + len(case))
+    NI, B, L = 4095, 6000, 10
+    w = random_din_weights(rng, E, NI, bias_std=0.01)
+    if case == "wide_range":
+        emb = w[:NI * E].reshape(NI, E)
+        emb[:, : E // 4] *= 2.0 ** -12
+        emb[:, E // 4: E // 2] *= 2.0 ** -6
+        l1 = w[NI * E + E * E: NI * E + 3 * E * E].reshape(E, 2 * E)
+        l1[:, 1:E:3] *= 2.0 ** -11
+        l1[:, E + 2::5] *= 2.0 ** -9          # W1b columns too: M = W1b att.W inherits the range
+    if case == "big_bias":
+        w[NI * E + 3 * E * E: NI * E + 3 * E * E + E] = rng.normal(0, 3.0, E).astype(np.float32)    # |b1| >> |W1a q|
+    codes = rng.integers(0, NI, B).astype(np.int32)
+    hist = rng.integers(0, NI, (B, L)).astype(np.int32)
+    hist[rng.random((B, L)) < 0.25] = -1
+    hist[0] = -1
+    pad = np.flatnonzero(hist.reshape(-1) < 0).astype(np.int32)
+    exact = oracle.Din(w.astype(np.float64), E, L, NI).forward(codes, hist, pad)
+    ref32 = oracle.Din(w, E, L, NI).forward(codes, hist, pad)
+    eng = Engine(0); eng.load_weights_din(w, E, NI)
+    res = {}
+    for mode in ("split_f16", "f32"):
+        eng.set_scorer_mode(mode)
+        got = eng.din_forward(codes, hist, pad)
+        assert (np.abs(got - ref32) <= ATOL + RTOL * np.abs(ref32)).all(), mode
+        res[mode] = _errs(got, exact)
+    eng.close()
+    (rs, ms), (rf, mf), (ro, mo) = res["split_f16"], res["f32"], _errs(ref32, exact)
+    line = dict(kernel="rows", E=E, case=case, rows=B, max_abs_logit=float(np.abs(exact).max()), split_rms=rs, split_max=ms,
+                f32_mfma_rms=rf, f32_mfma_max=mf, cpu_oracle_f32_rms=ro, cpu_oracle_f32_max=mo)
+    print("rows-split-vs-exact:", json.dumps(line))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "split_error.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    assert rs <= 1.25 * rf and ms <= 1.25 * mf + 1e-9, line
+    assert rs <= ro * 1.05, line
+
+
 # --------------------------------------------------------------------------------------------- OTM: exact integer replay
 def _otm_replay(oracle, tc, ts, tn, beam, start_level, leaf_level, final_ids):
     """buildBeamNodes on the device's scores: children of every level must be exactly what the device expanded."""
