@@ -1623,6 +1623,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
   return rc;
 }
 
+#include "jtm_rebalance_dev.hip.inc"
 #include "jtm_host.hip.inc"
 #include "train_host.hip.inc"
 #include "sampler.hip.inc"

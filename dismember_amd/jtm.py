@@ -7,6 +7,7 @@ the greedy re-balance is the exact host logic of dm_jtm_rebalance.  Items are it
 """
 import ctypes as C
 
+import os
 import numpy as np
 
 from . import _native as N
@@ -114,18 +115,30 @@ class JTM:
 
     def _optimize(self, proj, weight_fn, timing, as_array, t_up):
         import time
-        t_sc = t_rb = t_host = 0.0
+        t_sc = t_rb = t_host = t_step = 0.0
         c1 = lv = None
+        fused = os.environ.get("DM_JTM_FUSED", "1") != "0"
         for old_level in range(0, self.max_level, self.gap):
             level = min(self.max_level, old_level + self.gap)
             t0 = time.perf_counter()
-            w = (weight_fn or self.child_weights)(proj, old_level, level)
-            t1 = time.perf_counter()
             if c1 is None:                                     # the items' codes do not change during a run: level of each, once
                 c1 = self.item_code.astype(np.int64) + 1
                 lv = (np.frexp(c1.astype(np.float64))[1] - 1).astype(np.int64)
             old_node = ((c1 >> np.maximum(lv - level, 0)) - 1).astype(np.int32)     # JTMTree.getAncestorAtLevel
             max_assign = 1 << (self.max_level - level)         # TreeLearning.scala:56
+            if weight_fn is None and self.comm is None and getattr(self, "_cached", False) and fused:
+                # single rank, rows cached: scoring and re-balance of the step in one call, weights never leave the device
+                new = np.empty_like(proj)
+                t1 = time.perf_counter()
+                self.engine._chk(N.lib().dm_jtm_step_cached(self.engine._h, _p(proj, N.i32p), _p(old_node, N.i32p), proj.size, old_level, level,
+                                                            int(self.hierarchical), self.min_level, int(self.use_mask), int(max_assign), _p(new, N.i32p)))
+                t_host += t1 - t0; t_step += time.perf_counter() - t1
+                proj = new
+                continue
+            t_host += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            w = (weight_fn or self.child_weights)(proj, old_level, level)
+            t1 = time.perf_counter()
             w = np.ascontiguousarray(w, np.float32)
             new = np.empty_like(proj)                          # every parent node of the level in one call
             t2 = time.perf_counter()
@@ -135,7 +148,7 @@ class JTM:
             t_sc += t1 - t0; t_host += t2 - t1; t_rb += t3 - t2
             proj = new
         if timing is not None:
-            timing.update(scoring_s=t_sc, rebalance_s=t_rb, host_glue_s=t_host, rows_upload_s=t_up)
+            timing.update(scoring_s=t_sc, rebalance_s=t_rb, host_glue_s=t_host, rows_upload_s=t_up, fused_step_s=t_step)
         if as_array:
             return proj
         return dict(zip(self.items.tolist(), proj.tolist()))

@@ -190,6 +190,13 @@ int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *r
 int dm_jtm_cache_rows(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, int64_t n_items, int L);
 int dm_jtm_child_weights_cached(dm_handle_t h, const int32_t *item_node, int64_t i_lo, int64_t n_items, int old_level, int level,
                                 int hierarchical, int min_level, int use_mask, float *weights);
+/* One whole gap step of JTM.optimize (JTM.scala:36-72) over the cached catalogue on the device: the child weights of every item
+ * (as dm_jtm_child_weights_cached) and the greedy re-balance of every parent node of old_level (as dm_jtm_rebalance_all) with the
+ * [n_items x 2^gap] weight matrix kept in HBM.  item_node [n_items] = current node of every item, old_node [n_items] =
+ * tree.getAncestorAtLevel(item, level); out_node [n_items] = the item's node at `level` after the step.  n_items must be the
+ * cached catalogue's size (single-rank runs; sharded runs keep the two separate calls around their all-gather). */
+int dm_jtm_step_cached(dm_handle_t h, const int32_t *item_node, const int32_t *old_node, int64_t n_items, int old_level, int level,
+                       int hierarchical, int min_level, int use_mask, int max_assign, int32_t *out_node);
 /* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable
  * descending), first choice, greedy capacity-bounded reBalance (:217-265).  old_node [n] =
  * tree.getAncestorAtLevel(item, level); out_node [n] = assigned child code (-1: dropped by the greedy loop).

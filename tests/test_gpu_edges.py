@@ -246,6 +246,88 @@ def test_jtm_rebalance_large_parent_equals_oracle(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("case", ["root", "four_parents", "many_parents", "gap3_tight", "gap1", "nan_zero"])
+def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
+    """dm_jtm_rebalance_all runs every parent of a level on the device (jtm_rebalance_dev.hip.inc: rounds of stable compaction +
+    one stable 64-bit radix sort on (parent | moved | descending weight key)); DM_JTM_REBALANCE=host keeps the per-parent host
+    logic.  Both must give the oracle's reBalance (TreeLearning.scala:217-265) item for item: crowded ties, cascading overflow,
+    capacity too small for everyone (dropped items keep their node), NaN and signed zeros in the weights."""
+    import ctypes as C
+    from dismember_amd import Engine
+    from dismember_amd import _native as N
+    rng = np.random.default_rng(len(case) * 7 + 1)
+    cfg = dict(root=(120_000, 0, 2, 1.02), four_parents=(90_000, 2, 2, 1.0), many_parents=(200_000, 9, 2, 1.3), gap3_tight=(50_000, 3, 3, 0.8),
+               gap1=(40_000, 5, 1, 1.0), nan_zero=(30_000, 1, 2, 1.05))[case]
+    n, old_level, gap, slack = cfg
+    level, C_ = old_level + gap, 1 << gap
+    P = 1 << old_level
+    lo = P - 1
+    item_node = (lo + rng.integers(0, P, n)).astype(np.int32)
+    w = (rng.integers(0, 6, (n, C_)).astype(np.float32) - 2.0) / 2.0
+    w[:, 0] += 1.0
+    if case == "nan_zero":
+        w[rng.random((n, C_)) < 0.05] = np.nan
+        w[rng.random((n, C_)) < 0.05] = -0.0
+        w[rng.random((n, C_)) < 0.05] = 0.0
+    first = (item_node.astype(np.int64) << gap) + C_ - 1
+    old_node = (first + rng.integers(0, C_, n)).astype(np.int32)
+    old_node[rng.random(n) < 0.1] = -7                                   # items that sat elsewhere: "moved" for every child
+    max_assign = max(1, int(np.ceil(n / (P * C_) * slack)))
+    eng = Engine(0)
+    outs = {}
+    for mode in ("device", "host"):
+        os.environ["DM_JTM_REBALANCE"] = mode
+        try:
+            out = np.empty(n, np.int32)
+            eng._chk(N.lib().dm_jtm_rebalance_all(eng._h, w.ctypes.data_as(N.f32p), old_node.ctypes.data_as(N.i32p), item_node.ctypes.data_as(N.i32p),
+                                                  n, old_level, level, max_assign, out.ctypes.data_as(N.i32p)))
+            outs[mode] = out
+        finally:
+            del os.environ["DM_JTM_REBALANCE"]
+    eng.close()
+    assert np.array_equal(outs["device"], outs["host"]), (case, int((outs["device"] != outs["host"]).sum()))
+    ref = np.empty(n, np.int32)
+    for p in np.unique(item_node):                                       # the oracle, parent by parent
+        idx = np.flatnonzero(item_node == p)
+        r = np.asarray(oracle.jtm_rebalance(np.arange(idx.size, dtype=np.int32), w[idx], old_node[idx], int(p), old_level, level, max_assign))
+        ref[idx] = np.where(r >= 0, r, p)
+        if case == "many_parents" and p > lo + 40:
+            ref[idx] = outs["host"][idx]                                 # 512 parents: the oracle checks the first 40, host == device the rest
+    assert np.array_equal(outs["device"], ref), (case, int((outs["device"] != ref).sum()))
+    if slack < 1.0:
+        assert (outs["device"] == item_node).any()                       # somebody was dropped and kept the old node
+
+
+def test_jtm_fused_device_steps_equal_separate_host_steps():
+    """JTM.optimize over a 20 000-item catalogue: every gap step as ONE call (dm_jtm_step_cached: scoring, weights kept in HBM,
+    device re-balance) gives the projection of the separate dm_jtm_child_weights_cached + host dm_jtm_rebalance_all calls, and
+    it is a bijection onto the leaves (jtm/src/test/scala/JtmSpec.scala:37-51)."""
+    from dismember_amd import Engine
+    from dismember_amd.jtm import JTM
+    items, depth, E, L, nrow = 20_000, 15, 32, 10, 3
+    rng = np.random.default_rng(5)
+    tree = synth.make_tree(items, depth, rng)
+    eng = Engine(0)
+    eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth); eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+    eng.load_weights_din_synthetic(E, (1 << (depth + 1)) - 1, 11, tree_depth=depth, rho=0.9)
+    hist = synth.make_users(tree["leaf_ids"], 4096, L, np.random.default_rng(1))
+    order = np.argsort(tree["leaf_ids"], kind="stable")
+    pick = np.random.default_rng(2).integers(0, len(hist), size=items * nrow)
+    jt = JTM.from_arrays(eng, tree["leaf_ids"][order], tree["leaf_codes"][order], depth, np.arange(items + 1, dtype=np.int64) * nrow,
+                         hist[pick].reshape(-1), gap=2, seq_len=L)
+    tim = {}
+    fused = jt.optimize(as_array=True, timing=tim)
+    assert tim["fused_step_s"] > 0 and tim["scoring_s"] == 0
+    os.environ["DM_JTM_FUSED"] = "0"; os.environ["DM_JTM_REBALANCE"] = "host"
+    try:
+        sep = jt.optimize(as_array=True)
+    finally:
+        del os.environ["DM_JTM_FUSED"], os.environ["DM_JTM_REBALANCE"]
+    eng.close()
+    assert np.array_equal(fused, sep), int((fused != sep).sum())
+    assert np.unique(fused).size == items and fused.min() >= (1 << depth) - 1 and fused.max() <= (1 << (depth + 1)) - 2
+
+
 def test_otm_device_resident_request_equals_host_path():
     """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
     from dismember_amd import Engine

@@ -389,6 +389,13 @@ def test_jtm_optimize_end_to_end(engine_fixture, oracle, oracle_tree, oracle_din
         oracle_tree, oracle_din32, jtm.items, jtm.row_off, jtm.row_ids, node, 10, ol, lv))
     same = sum(int(proj[i] == ref[i]) for i in proj)
     assert same >= 0.9 * len(proj), same
+    # the fused gap step (dm_jtm_step_cached: weights stay in HBM, device re-balance) == the two separate calls with the host logic
+    os.environ["DM_JTM_FUSED"] = "0"; os.environ["DM_JTM_REBALANCE"] = "host"
+    try:
+        sep = jtm.optimize()
+    finally:
+        del os.environ["DM_JTM_FUSED"], os.environ["DM_JTM_REBALANCE"]
+    assert sep == proj
 
 
 # --------------------------------------------------------------------------- training step
