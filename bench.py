@@ -479,6 +479,7 @@ def main():
                                 % (items_s.size, nrow, depth, steps_j, din_rows),
                     "seconds": dtf, "items_per_s": world * items_s.size / dtf, "din_rows_per_s": world * din_rows / dtf,
                     "scoring_s": tim.get("scoring_s"), "rebalance_s": tim.get("rebalance_s"), "host_glue_s": tim.get("host_glue_s"),
+                    "rebalance": "on the device (dm_jtm_step_cached: weights stay in HBM)" if tim.get("fused_step_s") else "host",
                     "host_preparation_s": prep,
                     "bijection_onto_leaves": bool(np.unique(projf).size == projf.size and int(projf.min()) >= first_leaf)}
         del jtf, row_ids, pick, projf

@@ -11,6 +11,7 @@
 #include <thread>
 #include <utility>
 #include <cerrno>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -64,6 +65,7 @@ struct dm_ctx {
   bool beam_w = true;          // split scorer on the one-wave-per-SIMD kernel (beam_kernel_w.hip.inc); DM_BEAM_W=0 in the environment selects the LDS-fed kernel
   bool split_dirty = true;
   void *d_wsplit = nullptr;
+  double jtm_score_s = 0, jtm_rebal_s = 0;   // dm_jtm_last_step_seconds
   void *d_rows_split = nullptr;   // general-rows split kernel: fp16 hi / lo planes of W1a and M = W1b att.W, then M in fp32
   int sh_r = 0; bool rows_split_dirty = true;
   void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)

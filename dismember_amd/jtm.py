@@ -133,6 +133,9 @@ class JTM:
                 self.engine._chk(N.lib().dm_jtm_step_cached(self.engine._h, _p(proj, N.i32p), _p(old_node, N.i32p), proj.size, old_level, level,
                                                             int(self.hierarchical), self.min_level, int(self.use_mask), int(max_assign), _p(new, N.i32p)))
                 t_host += t1 - t0; t_step += time.perf_counter() - t1
+                a_, b_ = C.c_double(0), C.c_double(0)
+                self.engine._chk(N.lib().dm_jtm_last_step_seconds(self.engine._h, C.byref(a_), C.byref(b_)))
+                t_sc += a_.value; t_rb += b_.value
                 proj = new
                 continue
             t_host += time.perf_counter() - t0

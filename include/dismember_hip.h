@@ -197,6 +197,8 @@ int dm_jtm_child_weights_cached(dm_handle_t h, const int32_t *item_node, int64_t
  * cached catalogue's size (single-rank runs; sharded runs keep the two separate calls around their all-gather). */
 int dm_jtm_step_cached(dm_handle_t h, const int32_t *item_node, const int32_t *old_node, int64_t n_items, int old_level, int level,
                        int hierarchical, int min_level, int use_mask, int max_assign, int32_t *out_node);
+/* measurement: seconds the last dm_jtm_step_cached spent in its scoring pass and in its re-balance (copies included) */
+int dm_jtm_last_step_seconds(dm_handle_t h, double *scoring_s, double *rebalance_s);
 /* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable
  * descending), first choice, greedy capacity-bounded reBalance (:217-265).  old_node [n] =
  * tree.getAncestorAtLevel(item, level); out_node [n] = assigned child code (-1: dropped by the greedy loop).

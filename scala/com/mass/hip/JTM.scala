@@ -18,19 +18,20 @@ class JTM(engine: HipEngine, itemIds: Array[Int], itemCodes: Array[Int], maxLeve
   def optimize(): Map[Int, Int] = {
     val n = itemIds.length
     var node = new Array[Int](n)                                           // every item starts at the root
-    var oldLevel = 0
-    while (oldLevel < maxLevel) {
-      val level = math.min(maxLevel, oldLevel + gap)
-      val nchild = 1 << (level - oldLevel)
-      val weights = new Array[Float](n * nchild)
-      Native.jtmChildWeights(engine.handle, rowOff, rowItemIds, node, n.toLong, seqLen, oldLevel, level,
-        if (hierarchical) 1 else 0, minLevel, if (useMask) 1 else 0, weights)
-      val oldNode = itemCodes.map(ancestorAtLevel(_, level))
-      val out = new Array[Int](n)
-      Native.jtmRebalanceAll(engine.handle, weights, oldNode, node, n.toLong, oldLevel, level, 1 << (maxLevel - level), out)
-      node = out
-      oldLevel = level
-    }
+    // itemSequenceMap goes to the device once; every gap step is one call (scoring + greedy re-balance, weights stay in HBM)
+    Native.jtmCacheRows(engine.handle, rowOff, rowItemIds, n.toLong, seqLen)
+    try {
+      var oldLevel = 0
+      while (oldLevel < maxLevel) {
+        val level = math.min(maxLevel, oldLevel + gap)
+        val oldNode = itemCodes.map(ancestorAtLevel(_, level))
+        val out = new Array[Int](n)
+        Native.jtmStepCached(engine.handle, node, oldNode, n.toLong, oldLevel, level, if (hierarchical) 1 else 0, minLevel,
+          if (useMask) 1 else 0, 1 << (maxLevel - level), out)
+        node = out
+        oldLevel = level
+      }
+    } finally Native.jtmCacheRows(engine.handle, null, null, 0L, seqLen)
     itemIds.zip(node).toMap
   }
 }

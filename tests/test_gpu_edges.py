@@ -317,7 +317,7 @@ def test_jtm_fused_device_steps_equal_separate_host_steps():
                          hist[pick].reshape(-1), gap=2, seq_len=L)
     tim = {}
     fused = jt.optimize(as_array=True, timing=tim)
-    assert tim["fused_step_s"] > 0 and tim["scoring_s"] == 0
+    assert tim["fused_step_s"] > 0 and tim["scoring_s"] > 0 and tim["rebalance_s"] > 0
     os.environ["DM_JTM_FUSED"] = "0"; os.environ["DM_JTM_REBALANCE"] = "host"
     try:
         sep = jt.optimize(as_array=True)
