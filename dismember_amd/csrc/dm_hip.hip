@@ -68,6 +68,8 @@ struct dm_ctx {
   double jtm_score_s = 0, jtm_rebal_s = 0;   // dm_jtm_last_step_seconds
   void *d_rows_split = nullptr;   // general-rows split kernel: fp16 hi / lo planes of W1a and M = W1b att.W, then M in fp32
   int sh_r = 0; bool rows_split_dirty = true;
+  bool emb_split_dirty = true;   // the pre-split copy of the table lags the scales (ensure_split_scales / ensure_split)
+  bool call_split = false;       // scorer arithmetic of the search being planned (split_for_call)
   void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)
   size_t emb_split_bytes = 0;
   unsigned *d_maxabs = nullptr;
@@ -750,11 +752,12 @@ static int launch_rows_E(dm_ctx *h, const RowsParams &p) {
 }
 
 static bool use_split(const dm_ctx *h);
-static int ensure_split(dm_ctx *h);
+static int ensure_split_scales(dm_ctx *h);
 static int split_shift(unsigned maxbits);
+static bool weights_in_motion(const dm_ctx *h);
 // fp16 planes of the general-rows split kernel (rows_kernel.hip.inc): follow the weights like the beam kernels' planes
 static int ensure_rows_split(dm_ctx *h) {
-  int rc = ensure_split(h);        // sh_e = the table's scale (one pass over the table per weight change, shared with the beam kernels)
+  int rc = ensure_split_scales(h);     // sh_e = the table's scale: one read of the table per weight change, shared with the beam kernels
   if (rc != DM_OK) return rc;
   if (!h->rows_split_dirty && h->d_rows_split) return DM_OK;
   const int E = h->embed;
@@ -791,7 +794,9 @@ static int launch_rows_split_E(dm_ctx *h, const RowsSplitParams &p) {
 // f32 general-rows forward on device buffers (asynchronous on the handle's stream)
 static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
                         int L, float *d_out) {
-  if (use_split(h)) {      // the default arithmetic for E = 32 / 64 / 128 (DM_SCORER_F32 keeps the fp32-input kernel below)
+  // the default arithmetic for E = 32 / 64 / 128 (DM_SCORER_F32 keeps the fp32-input kernel below).  While a training loop keeps
+  // moving the weights (AUTO mode) a batch below ~4 M rows is cheaper on the fp32-input kernel than the table scan for the new scale.
+  if (use_split(h) && !(weights_in_motion(h) && B < ((int64_t)1 << 22))) {
     int rc = ensure_rows_split(h);
     if (rc != DM_OK) return rc;
     RowsSplitParams q;
@@ -879,6 +884,22 @@ static bool use_split(const dm_ctx *h) {
   return (h->scorer_mode == DM_SCORER_SPLIT_F16 || h->scorer_mode == DM_SCORER_AUTO) && h->embed % 32 == 0;
 }
 
+// AUTO mode inside a training loop: the split scorer's scales / fp16 copies are stale after every Adam step, and refreshing them is a
+// pass (or three) over the whole table.  A request that is small next to that takes the fp32-input kernels, which read the fp32
+// table as it is; both arithmetics meet the same tolerance.  An explicit DM_SCORER_SPLIT_F16 is always honoured.
+static bool weights_in_motion(const dm_ctx *h) {
+  return h->scorer_mode == DM_SCORER_AUTO && h->train_ready && (h->split_dirty || h->f32_mirror_dirty);
+}
+static bool split_for_call(const dm_ctx *h, int64_t U, int max_beam) {
+  if (!use_split(h)) return false;
+  if (weights_in_motion(h) || (h->scorer_mode == DM_SCORER_AUTO && h->train_ready && h->emb_split_dirty)) {
+    const double rebuild_s = 3.0e-5 + 3.0 * (double)h->num_index * h->embed * 4 / 3.0e12;   // launches + read-back, then scan + read + write of the table at ~3 TB/s
+    const double extra_s = (double)U * max_beam * 7.0e-9;                             // fp32-input kernel: ~7 ns more per (user, beam slot)
+    if (extra_s < rebuild_s) return false;
+  }
+  return true;
+}
+
 // fp64 parity mode of the OTM search (otm64.hip.inc): in effect when f64 weights are loaded and the scorer mode is AUTO or F64
 static bool use_f64_beam(const dm_ctx *h) {
   return h->dtype == DM_F64 && (h->scorer_mode == DM_SCORER_AUTO || h->scorer_mode == DM_SCORER_F64);
@@ -892,7 +913,8 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   const int kq = (L + 3) / 4;
   int nteams = 0;
   pl->wkernel = false;
-  if (use_split(h) && h->beam_w) {
+  h->call_split = split_for_call(h, U, max_beam);
+  if (h->call_split && h->beam_w) {
     // split-fp16 scorer: one-wave teams, four per workgroup, W1a in registers; falls back when the frontier outgrows LDS
     BeamWLds l = dm_beamw_lds(h->embed, cap, pcap, kq);
     if (l.total <= 160 * 1024) { nteams = DMW_NWAVES; pl->lds = l.total; pl->wkernel = true; }
@@ -902,7 +924,7 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   // chain sort -> expand -> gather -> score of a level, and eight users per CU in flight instead of four
   if (!nteams)
   for (int cand = (pcap <= 256 ? 8 : 4); cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, use_split(h));
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, h->call_split);
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
   if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (about 2*beam*28 bytes + weights must fit 160 KiB)");
@@ -1053,7 +1075,9 @@ static int split_shift(unsigned maxbits) {
   return sh;
 }
 
-static int ensure_split(dm_ctx *h) {
+// scales (2^sh_e from max|emb|: one read of the table; 2^sh_w from max|W1a|) and the fp16 planes of W1a: what every split kernel
+// needs.  The pre-split copy of the table (ensure_split) is a second, larger step only the beam kernels take.
+static int ensure_split_scales(dm_ctx *h) {
   if (!h->split_dirty && h->d_wsplit) return DM_OK;
   const int E = h->embed;
   if (E % 32 != 0) return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size that is a multiple of 32");
@@ -1071,6 +1095,17 @@ static int ensure_split(dm_ctx *h) {
   hipLaunchKernelGGL(dm_build_wsplit_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->d_wfrag, E, ldexpf(1.0f, h->sh_w),
                      (_Float16 *)h->d_wsplit);
   HIPCHK(h, hipGetLastError());
+  h->split_dirty = false;
+  h->emb_split_dirty = true;
+  h->rows_split_dirty = true;
+  return DM_OK;
+}
+
+static int ensure_split(dm_ctx *h) {
+  int rc = ensure_split_scales(h);
+  if (rc != DM_OK) return rc;
+  if (!h->emb_split_dirty && h->d_emb_split) return DM_OK;
+  const int E = h->embed;
   {
     // the beam kernels gather pre-split rows: a second copy of the table (same size), rebuilt whenever the weights change
     const size_t bytes = (size_t)h->num_index * E * 4;
@@ -1083,8 +1118,7 @@ static int ensure_split(dm_ctx *h) {
                        (_Float16 *)h->d_emb_split);
     HIPCHK(h, hipGetLastError());
   }
-  h->split_dirty = false;
-  h->rows_split_dirty = true;
+  h->emb_split_dirty = false;
   return DM_OK;
 }
 
@@ -1099,7 +1133,7 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
   // the brute-force recall oracle (mode 2) always scores with the fp32-input MFMA
   if (h->scorer_mode == DM_SCORER_SPLIT_F16 && h->embed % 32 != 0)
     return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size of 32, 64 or 128");
-  if (use_split(h) && p.mode != 2) {
+  if (h->call_split && p.mode != 2) {
     int rc = ensure_split(h);
     if (rc != DM_OK) return rc;
     p.wsplit = (const dm_h8 *)h->d_wsplit;

@@ -328,6 +328,37 @@ def test_jtm_fused_device_steps_equal_separate_host_steps():
     assert np.unique(fused).size == items and fused.min() >= (1 << depth) - 1 and fused.max() <= (1 << (depth + 1)) - 2
 
 
+def test_small_searches_inside_a_training_loop_skip_the_table_rebuild(oracle):
+    """AUTO mode: after an Adam step the split scorer's scale and fp16 copy of the table are stale; a small request takes the
+    fp32-input kernel (reads the fp32 table as it is) instead of re-scanning the whole table, an explicit split_f16 request and a
+    model that is not training keep the split kernel; results stay inside the stated tolerance of the oracle either way."""
+    from dismember_amd import Engine
+    from test_gpu_parity import make_engine, replay_and_check
+    rng = np.random.default_rng(77)
+    depth, n_items, E, beam, topk = 9, 400, 32, 20, 10
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    eng = make_engine(t, w, E)
+    seqs = random_histories(rng, t["leaf_ids"], 6, 10)
+    eng.tdm_beam_search(seqs, beam, topk)
+    assert eng.last_beam_kernel().startswith("dm_beam_w_kernel")
+    eng.train_init(lr=1e-3)
+    codes = rng.integers(0, NI, 64).astype(np.int32); hist = rng.integers(0, NI, (64, 10)).astype(np.int32)
+    eng.train_forward_backward(codes, hist, None, (rng.random(64) < 0.5).astype(np.float32))
+    eng.adam_step()
+    w2 = eng.train_download()
+    eng.tdm_beam_search(seqs, beam, topk)
+    assert eng.last_beam_kernel() == "dm_beam_kernel<32, 3, false>"
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    replay_and_check(otree, oracle.Din(w2, E, 10, NI), eng, seqs, beam, topk, use_mask=True)
+    eng.set_scorer_mode("split_f16")
+    eng.tdm_beam_search(seqs, beam, topk)
+    assert eng.last_beam_kernel().startswith("dm_beam_w_kernel")
+    replay_and_check(otree, oracle.Din(w2, E, 10, NI), eng, seqs, beam, topk, use_mask=True)
+    eng.close()
+
+
 def test_otm_device_resident_request_equals_host_path():
     """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
     from dismember_amd import Engine
