@@ -560,9 +560,11 @@ def main():
             dtt = max_over_ranks(time.perf_counter() - t0)
             nparam = ni2 * E + 3 * E * E + 2 * E + 1
             train = {"workload": "TDM train step on the 1M-item tree: %d targets -> %d expanded rows per worker (level-wise negatives drawn on the device), "
-                                 "DIN fwd+bwd, gradient exchange (dm_train_sync_gradients: RCCL inside the library), dense Adam over %d parameters" % (Tt, Tt * per, nparam),
+                                 "DIN fwd+bwd, gradient exchange (dm_train_sync_gradients: RCCL inside the library), Adam over %d parameters "
+                                 "(the reference's dense update, evaluated on the rows a gradient has ever reached: bit-identical, dm_adam_last_step_rows)" % (Tt, Tt * per, nparam),
                      "ms_per_step": dtt / nts * 1e3, "rows_per_s": world * Tt * per * nts / dtt, "loss": tloss,
-                     "adam_stream_bytes_per_step": 8 * 4 * nparam, "workers": world,
+                     "adam_rows_visited_last_step": eng.adam_last_step_rows()[0], "adam_active_rows_path": eng.adam_last_step_rows()[1],
+                     "adam_dense_stream_bytes_per_step": 8 * 4 * nparam, "workers": world,
                      "gradient_exchange": ("dm_train_sync_gradients over dm_comm (%s)" % comm_transport) if comm is not None else "single worker"}
             if comm is not None:
                 st = eng.train_sync_stats()
@@ -706,10 +708,11 @@ def main():
             npar6 = ni6 * E + 3 * E * E + 2 * E + 1
             otm64["train_iteration"] = {
                 "workload": "one OTM LocalOptimizer iteration in fp64: %d users per worker, pseudo targets + beam nodes, then %d levels x "
-                            "(forward/backward on %d rows, gradient exchange, dense fp64 Adam over %d parameters)"
+                            "(forward/backward on %d rows, gradient exchange, fp64 Adam over %d parameters: the dense update on the rows a gradient has ever reached, bit-identical)"
                             % (Ut6, len(losses6), Ut6 * 2 * a.beam, npar6),
                 "seconds": dtt6, "levels": len(losses6), "loss_first_level": float(losses6[0]), "loss_last_level": float(losses6[-1]),
-                "adam_stream_bytes_per_level": 8 * 8 * npar6, "train_init_s": t_init6, "workers": world,
+                "adam_rows_visited_last_step": eng.adam_last_step_rows()[0], "adam_active_rows_path": eng.adam_last_step_rows()[1],
+                "adam_dense_stream_bytes_per_level": 8 * 8 * npar6, "train_init_s": t_init6, "workers": world,
                 "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker"}
         except Exception as ex:
             otm64 = dict(otm64 or {}, error=repr(ex))

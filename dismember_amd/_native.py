@@ -77,6 +77,7 @@ SIGNATURES = {
     "dm_train_init": (C.c_int, [C.c_void_p, C.POINTER(AdamOpts)]),
     "dm_train_forward_backward": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int64, f32p, C.c_int64, C.c_int, f32p]),
     "dm_adam_step": (C.c_int, [C.c_void_p, C.c_float]),
+    "dm_adam_last_step_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dm_train_last_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "dm_train_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "dm_train_dense_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), i64p]),

@@ -93,6 +93,10 @@ struct dm_ctx {
   unsigned *d_touch_bits = nullptr;
   int32_t *d_touch_list = nullptr;
   unsigned long long *d_touch_cnt = nullptr;
+  unsigned *d_active_bits = nullptr;   // rows a gradient has ever reached since dm_train_init (the rows the Adam step has to visit)
+  int32_t *d_active_list = nullptr;
+  unsigned long long *d_active_cnt = nullptr;
+  int adam_last_sparse = 0; unsigned long long adam_last_rows = 0;
   size_t touch_cap = 0, touch_ub = 0;   // list capacity; host-side upper bound of its length since the last Adam step
   // measurement
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -338,6 +342,7 @@ static void free_weights(dm_ctx *h) {
   h->d_compact = nullptr; h->d_emb32 = nullptr; h->emb32_owned = false; h->d_wfrag = nullptr;
   dm_free_ptr(h->d_grad); dm_free_ptr(h->d_adam_s); dm_free_ptr(h->d_adam_r); dm_free_ptr(h->d_loss); dm_free_ptr(h->d_attTA);
   dm_free_ptr(h->d_w1aTA); dm_free_ptr(h->d_w1bTA); dm_free_ptr(h->d_touch_bits); dm_free_ptr(h->d_touch_list); dm_free_ptr(h->d_touch_cnt);
+  dm_free_ptr(h->d_active_bits); dm_free_ptr(h->d_active_list); dm_free_ptr(h->d_active_cnt); h->d_active_bits = nullptr; h->d_active_list = nullptr; h->d_active_cnt = nullptr;
   h->d_grad = h->d_adam_s = h->d_adam_r = h->d_loss = nullptr; h->d_attTA = h->d_w1aTA = h->d_w1bTA = nullptr;
   h->d_touch_bits = nullptr; h->d_touch_list = nullptr; h->d_touch_cnt = nullptr; h->train_ready = false; h->touch_cap = 0; h->touch_ub = 0;
   h->d_afrag = h->d_bfrag = nullptr; h->d_attA = h->d_w1aA = h->d_w1bA = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;

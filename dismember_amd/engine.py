@@ -405,6 +405,12 @@ class Engine:
     def adam_step(self, grad_scale=1.0):
         self._chk(N.lib().dm_adam_step(self._h, float(grad_scale)))
 
+    def adam_last_step_rows(self):
+        """(rows visited by the last Adam step, True when it took the active-rows path)."""
+        r, a = C.c_uint64(0), C.c_int(0)
+        self._chk(N.lib().dm_adam_last_step_rows(self._h, C.byref(r), C.byref(a)))
+        return int(r.value), bool(a.value)
+
     def train_download(self, what="weights"):
         n = self.num_index * self.E + 3 * self.E * self.E + 2 * self.E + 1
         out = np.empty(n, self.dtype)          # the loaded dtype: fp64 models train in fp64

@@ -242,6 +242,11 @@ int dm_train_init(dm_handle_t h, const dm_adam_opts *opts);
 int dm_train_forward_backward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
                               int64_t n_pad, const float *labels, int64_t B, int L, float *loss);
 int dm_adam_step(dm_handle_t h, float grad_scale);
+/* The step visits the embedding rows a gradient has ever reached since dm_train_init plus the small matrices: for every other row
+ * g = s = r = 0 and the reference's dense update leaves the weight bit-identical (0 / (sqrt(0) + eps) = 0, w + (-0) = w), so the result IS
+ * the dense Adam's, without streaming a table that cannot change (dense stream again once a quarter of the rows are active, when eps == 0,
+ * or with DM_ADAM_DENSE=1 in the environment).  Measurement: rows visited by the last step, and whether it took the active-rows path. */
+int dm_adam_last_step_rows(dm_handle_t h, uint64_t *rows, int *active_rows_only);
 int dm_train_last_loss(dm_handle_t h, double *loss);
 /* what: 0 weights, 1 gradient, 2 Adam s, 3 Adam r — host copy of the full compact-layout vector (tests, checkpoints) */
 int dm_train_download(dm_handle_t h, int what, void *out, int64_t n);

@@ -359,6 +359,49 @@ def test_small_searches_inside_a_training_loop_skip_the_table_rebuild(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_adam_step_over_active_rows_equals_dense_stream(dtype):
+    """dm_adam_step visits only the rows a gradient has ever reached (and the small matrices); for every other row the reference's
+    dense update is the identity on the bits (g = s = r = 0 -> w + (-0)).  Weights AND both Adam moments after several steps, with
+    rows touched in one step and left alone in the next, must equal the dense stream (DM_ADAM_DENSE=1) bit for bit; signed zeros
+    in the table survive."""
+    from dismember_amd import Engine
+    from dismember_amd import _native as N
+    E, NI, L = 32, 65535, 10
+    res = {}
+    for mode in ("active", "dense"):
+        rng = np.random.default_rng(3)
+        w = random_din_weights(rng, E, NI, dtype=dtype)
+        w[5 * E: 7 * E] = -0.0; w[7 * E: 9 * E] = 0.0
+        if mode == "dense":
+            os.environ["DM_ADAM_DENSE"] = "1"
+        try:
+            eng = Engine(0); eng.load_weights_din(w, E, NI)
+            eng.train_init(lr=1e-2)
+            for step in range(4):
+                # one gradient row per touched row, added once each: bitwise reproducible (the training kernels accumulate with
+                # float atomics, whose order is not)
+                rows = rng.choice(NI, 1500, replace=False).astype(np.int32)
+                rows = rows[(rows != 6) & (rows != 8)]                 # the signed-zero sentinels stay untouched
+                if step == 0:
+                    rows[:2] = (5, 7)
+                g = rng.normal(0, 1e-2, (rows.size, E)).astype(dtype)
+                d_r = eng.dev_alloc(rows.nbytes); d_g = eng.dev_alloc(g.nbytes)
+                eng.h2d(d_r, rows); eng.h2d(d_g, g)
+                eng._chk(N.lib().dm_train_add_rows(eng._h, d_r, d_g, rows.size))
+                eng.adam_step()
+                eng.dev_free(d_r); eng.dev_free(d_g)
+                nrows, active = eng.adam_last_step_rows()
+                assert active == (mode == "active") and (nrows <= 1500 * (step + 1) if active else nrows == NI)
+            res[mode] = (eng.train_download("weights"), eng.train_download("s"), eng.train_download("r"))
+            eng.close()
+        finally:
+            os.environ.pop("DM_ADAM_DENSE", None)
+    for a, b in zip(res["active"], res["dense"]):
+        assert a.dtype == dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert np.signbit(res["active"][0][6 * E: 7 * E]).all() and not np.signbit(res["active"][0][8 * E: 9 * E]).any()      # untouched signed zeros
+
+
 def test_otm_device_resident_request_equals_host_path():
     """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
     from dismember_amd import Engine

@@ -55,7 +55,7 @@ HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: writte
 # entry points that neither wait on peers / the network nor run a long device job: the only ones allowed a Critical region
 CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_memcpy_h2d", "dm_memcpy_d2h", "dm_kernel_timing_get",
                "dm_kernel_timing_get_kind", "dm_get_scorer_mode", "dm_comm_rank", "dm_device_count", "dm_last_scored_rows",
-               "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_comm_unique_id", "dm_dev_alloc", "dm_create"}
+               "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_adam_last_step_rows", "dm_comm_unique_id", "dm_dev_alloc", "dm_create"}
 JTYPE = {"jint": "Int", "jlong": "Long", "jfloat": "Float", "jdouble": "Double", "jbyte": "Byte"}
 
 
