@@ -70,6 +70,12 @@ struct dm_ctx {
   int sh_r = 0; bool rows_split_dirty = true;
   bool emb_split_dirty = true;   // the pre-split copy of the table lags the scales (ensure_split_scales / ensure_split)
   bool call_split = false;       // scorer arithmetic of the search being planned (split_for_call)
+  // incremental refresh inside a training loop (ensure_split_scales): the table changed only in the ACTIVE rows of the Adam step
+  bool table_dense_change = true;   // ... unless something rewrote it wholesale since the last full scan (load, dense Adam step, f64 -> f32 mirror)
+  bool sh_e_valid = false;          // sh_e comes from a full scan of the current table lineage
+  bool emb_split_need_full = true;  // d_emb_split is not (scale sh_e, stale in active rows only)
+  bool emb_split_patch = false;
+  unsigned long long active_rows_host = 0;   // length of the active-row list at the last Adam step
   void *d_emb_split = nullptr;     // pre-split table of the W kernel (beam_kernel_w.hip.inc)
   size_t emb_split_bytes = 0;
   unsigned *d_maxabs = nullptr;
@@ -334,7 +340,7 @@ static void free_weights(dm_ctx *h) {
   if (h->emb32_owned) dm_free_ptr(h->d_emb32);
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
-  dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true;
+  dm_free_ptr(h->d_wsplit); dm_free_ptr(h->d_maxabs); h->d_wsplit = nullptr; h->d_maxabs = nullptr; h->split_dirty = true; h->table_dense_change = true; h->sh_e_valid = false; h->emb_split_need_full = true;
   dm_free_ptr(h->d_rows_split); h->d_rows_split = nullptr; h->rows_split_dirty = true;
   dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
   dm_free_ptr(h->d_frag64); h->d_frag64 = nullptr; h->frag64_dirty = true;
@@ -574,7 +580,7 @@ static int load_weights_t(dm_ctx *h, int E, int64_t num_index, const T *w, int64
   int rc = upload_derived<T>(h, E, w + num_index * E);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true; h->table_dense_change = true;
   return DM_OK;
 }
 template <typename T>
@@ -616,7 +622,7 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
   HIPCHK(h, hipMemcpy(t.data(), d_compact + num_index * E, (size_t)tail * 4, hipMemcpyDeviceToHost));
   int rc = upload_derived<float>(h, E, t.data());
   if (rc != DM_OK) return rc;
-  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true; h->table_dense_change = true;
   return DM_OK;
 }
 
@@ -642,7 +648,7 @@ int dm_load_weights_din_dev_f64(dm_handle_t h, int E, int64_t num_index, double 
   int rc = upload_derived<double>(h, E, t.data());
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true;
+  h->embed = E; h->embed_log = E; h->num_index = num_index; h->w_loaded = true; h->split_dirty = true; h->table_dense_change = true;
   return DM_OK;
 }
 
@@ -898,7 +904,9 @@ static bool weights_in_motion(const dm_ctx *h) {
 static bool split_for_call(const dm_ctx *h, int64_t U, int max_beam) {
   if (!use_split(h)) return false;
   if (weights_in_motion(h) || (h->scorer_mode == DM_SCORER_AUTO && h->train_ready && h->emb_split_dirty)) {
-    const double rebuild_s = 3.0e-5 + 3.0 * (double)h->num_index * h->embed * 4 / 3.0e12;   // launches + read-back, then scan + read + write of the table at ~3 TB/s
+    const bool patchable = h->sh_e_valid && !h->table_dense_change && h->dtype == DM_F32;                       // only the Adam step's active rows are stale
+    const double rows_ = patchable ? (double)h->active_rows_host : (double)h->num_index;
+    const double rebuild_s = 3.0e-5 + 3.0 * rows_ * h->embed * 4 / (patchable ? 1.0e12 : 3.0e12);   // launches + read-back, then scan + read + write
     const double extra_s = (double)U * max_beam * 7.0e-9;                             // fp32-input kernel: ~7 ns more per (user, beam slot)
     if (extra_s < rebuild_s) return false;
   }
@@ -1066,6 +1074,34 @@ __global__ void dm_build_emb_split_kernel(const float *emb, int64_t num_index, i
   }
 }
 
+// the same two passes over a LIST of rows (the rows an Adam step can have moved: ensure_split_scales / ensure_split inside a training loop)
+__global__ void dm_maxabs_rows_kernel(const float *emb, const int32_t *rows, int64_t n_rows, int E, unsigned *out) {
+  unsigned m = 0;
+  const int64_t n = n_rows * E;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(emb[(int64_t)rows[t / E] * E + (t % E)]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ void dm_build_emb_split_rows_kernel(const float *emb, const int32_t *rows, int64_t n_rows, int E, float scale, _Float16 *out) {
+  const int64_t n8 = n_rows * (int64_t)(E / 8);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = rows[t / (E / 8)];
+    const int sg = (int)(t % (E / 8)), s_ = sg >> 2, g = sg & 3;
+    const float *src = emb + row * E + 32 * s_ + 4 * g;
+    _Float16 *dst = out + row * (int64_t)(2 * E) + (int64_t)sg * 16;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float x = src[16 * (i >> 2) + (i & 3)] * scale;
+      const _Float16 hi = (_Float16)x;
+      dst[i] = hi;
+      dst[8 + i] = (_Float16)(x - (float)hi);
+    }
+  }
+}
+
 // power-of-two shift that puts max|x| into [2^13, 2^14): every scaled value and every rounding of it stays below the fp16
 // maximum, and fp16 subnormals only start 2^27 below the largest element
 static int split_shift(unsigned maxbits) {
@@ -1088,14 +1124,29 @@ static int ensure_split_scales(dm_ctx *h) {
   if (E % 32 != 0) return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size that is a multiple of 32");
   if (!h->d_wsplit) ALLOC(h, h->d_wsplit, (size_t)E * E * 4);
   if (!h->d_maxabs) ALLOC(h, h->d_maxabs, 8);
-  HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, 8, h->stream));
-  hipLaunchKernelGGL(dm_maxabs_kernel, dim3(4096), dim3(256), 0, h->stream, h->d_emb32, h->num_index * (int64_t)E, h->d_maxabs);
-  hipLaunchKernelGGL(dm_maxabs_kernel, dim3(16), dim3(256), 0, h->stream, (const float *)h->d_wfrag, (int64_t)E * E, h->d_maxabs + 1);
-  HIPCHK(h, hipGetLastError());
+  // Inside a training loop whose Adam steps visit the active rows only, nothing else of the table has moved since the last full
+  // scan: the scale 2^sh_e stays (a power of two: exact) as long as the active rows still fit it, and only those rows are re-split.
+  bool patch = h->train_ready && h->sh_e_valid && !h->table_dense_change && h->d_active_list && h->dtype == DM_F32;
   unsigned mb[2];
-  HIPCHK(h, hipMemcpyAsync(mb, h->d_maxabs, 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->sh_e = split_shift(mb[0]);
+  for (;;) {
+    HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, 8, h->stream));
+    if (patch) {
+      if (h->active_rows_host)
+        hipLaunchKernelGGL(dm_maxabs_rows_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_emb32, h->d_active_list, (int64_t)h->active_rows_host, E, h->d_maxabs);
+    } else
+      hipLaunchKernelGGL(dm_maxabs_kernel, dim3(4096), dim3(256), 0, h->stream, h->d_emb32, h->num_index * (int64_t)E, h->d_maxabs);
+    hipLaunchKernelGGL(dm_maxabs_kernel, dim3(16), dim3(256), 0, h->stream, (const float *)h->d_wfrag, (int64_t)E * E, h->d_maxabs + 1);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(mb, h->d_maxabs, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (patch && mb[0] != 0 && split_shift(mb[0]) < h->sh_e) { patch = false; continue; }    // an active row outgrew the scale: full scan
+    break;
+  }
+  if (!patch) {
+    h->sh_e = split_shift(mb[0]);
+    h->sh_e_valid = true; h->table_dense_change = false; h->emb_split_need_full = true;
+  }
+  h->emb_split_patch = patch;
   h->sh_w = split_shift(mb[1]);
   hipLaunchKernelGGL(dm_build_wsplit_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->d_wfrag, E, ldexpf(1.0f, h->sh_w),
                      (_Float16 *)h->d_wsplit);
@@ -1111,18 +1162,24 @@ static int ensure_split(dm_ctx *h) {
   if (rc != DM_OK) return rc;
   if (!h->emb_split_dirty && h->d_emb_split) return DM_OK;
   const int E = h->embed;
-  {
-    // the beam kernels gather pre-split rows: a second copy of the table (same size), rebuilt whenever the weights change
-    const size_t bytes = (size_t)h->num_index * E * 4;
-    if (h->emb_split_bytes != bytes) {
-      dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
-      ALLOC(h, h->d_emb_split, bytes);
-      h->emb_split_bytes = bytes;
-    }
+  // the beam kernels gather pre-split rows: a second copy of the table (same size), refreshed whenever the weights change — as a whole,
+  // or in the active rows only when nothing else can have moved
+  const size_t bytes = (size_t)h->num_index * E * 4;
+  if (h->emb_split_bytes != bytes) {
+    dm_free_ptr(h->d_emb_split); h->d_emb_split = nullptr; h->emb_split_bytes = 0;
+    ALLOC(h, h->d_emb_split, bytes);
+    h->emb_split_bytes = bytes;
+    h->emb_split_need_full = true;
+  }
+  if (h->emb_split_need_full || !h->emb_split_patch) {
     hipLaunchKernelGGL(dm_build_emb_split_kernel, dim3(8192), dim3(256), 0, h->stream, h->d_emb32, h->num_index, E, ldexpf(1.0f, h->sh_e),
                        (_Float16 *)h->d_emb_split);
-    HIPCHK(h, hipGetLastError());
+    h->emb_split_need_full = false;
+  } else if (h->active_rows_host) {
+    hipLaunchKernelGGL(dm_build_emb_split_rows_kernel, dim3(1024), dim3(256), 0, h->stream, h->d_emb32, h->d_active_list, (int64_t)h->active_rows_host,
+                       E, ldexpf(1.0f, h->sh_e), (_Float16 *)h->d_emb_split);
   }
+  HIPCHK(h, hipGetLastError());
   h->emb_split_dirty = false;
   return DM_OK;
 }

@@ -335,7 +335,7 @@ def test_small_searches_inside_a_training_loop_skip_the_table_rebuild(oracle):
     from dismember_amd import Engine
     from test_gpu_parity import make_engine, replay_and_check
     rng = np.random.default_rng(77)
-    depth, n_items, E, beam, topk = 9, 400, 32, 20, 10
+    depth, n_items, E, beam, topk = 13, 3000, 32, 20, 10
     t = synthetic_tree(rng, depth, n_items)
     NI = (1 << (depth + 1)) - 1
     w = random_din_weights(rng, E, NI)
@@ -356,6 +356,16 @@ def test_small_searches_inside_a_training_loop_skip_the_table_rebuild(oracle):
     eng.tdm_beam_search(seqs, beam, topk)
     assert eng.last_beam_kernel().startswith("dm_beam_w_kernel")
     replay_and_check(otree, oracle.Din(w2, E, 10, NI), eng, seqs, beam, topk, use_mask=True)
+    # the split copies were refreshed in the Adam step's active rows only (704 of 16 383 rows can have moved): same results as an
+    # engine that loads the trained weights and splits the whole table
+    assert eng.adam_last_step_rows()[1]
+    got = eng.tdm_beam_search(seqs, beam, topk)
+    fresh = make_engine(t, w2, E)
+    fresh.set_scorer_mode("split_f16")
+    want = fresh.tdm_beam_search(seqs, beam, topk)
+    assert fresh.last_beam_kernel() == eng.last_beam_kernel()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    fresh.close()
     eng.close()
 
 
