@@ -411,3 +411,35 @@ def test_full_size_otm_fp64_depth24():
     ref32 = eng.din_forward(idf[0], np.tile(codes[1], (2 * beam, 1)), pad, L=L)
     assert (np.abs(scf[0] - ref32) <= ATOL + RTOL * np.abs(ref32)).all()
     eng.close()
+
+
+def test_otm_f64_register_sort_falls_back_when_scores_share_their_top_bits(oracle):
+    """The fp64 beam kernel prunes a level with a register sort on (top 53 bits of the Double.compare key, position) and redoes the
+    level with the exact LDS network when two DIFFERENT scores share those bits.  A model whose output bias dwarfs everything else
+    (scores = 3e4 + O(1e-9): all candidates share the prefix) must still return what the exact network returns (DM_OTM64_LDS_SORT=1)
+    and replay exactly (CandidateSearcher.buildBeamNodes on the device's own scores); so must an ordinary model."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(99)
+    E, leaf_level, beam, U, L = 32, 9, 100, 6, 10
+    NI = (1 << (leaf_level + 1)) - 1
+    for big_bias in (True, False):
+        w = random_din_weights(rng, E, NI, dtype=np.float64, std=1e-3 if big_bias else 0.2, bias_std=0.0)
+        if big_bias:
+            w[-1] = 3.0e4
+        codes = rng.integers((1 << leaf_level) - 1, NI, (U, L)).astype(np.int32)
+        start_level = beam.bit_length() - 1
+        outs = []
+        for force in ("0", "1"):
+            os.environ["DM_OTM64_LDS_SORT"] = force
+            try:
+                eng = Engine(0); eng.load_weights_din(w, E, NI)
+                ids, sc, cnt, tc, ts, tn = eng.otm_beam_search_f64(codes, beam, leaf_level, trace_levels=leaf_level - start_level)
+                assert eng.last_beam_kernel().startswith("dm_beam64_kernel")
+                eng.close()
+            finally:
+                del os.environ["DM_OTM64_LDS_SORT"]
+            _otm_replay(oracle, tc, ts, tn, beam, start_level, leaf_level, ids)
+            outs.append((ids, sc, cnt))
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+        if big_bias:
+            assert np.ptp(outs[0][1]) < 1e-6 and abs(outs[0][1].mean() - 3.0e4) < 1.0      # the scores really do share their top bits
