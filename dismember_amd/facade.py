@@ -76,16 +76,18 @@ class OTM:
         single = seq.ndim == 1
         if single:
             seq = seq[None, :]
-        codes = np.array([[self.item_id_mapping.get(int(i), -1) for i in row] for row in seq], dtype=np.int32)
+        get = self.item_id_mapping.get
+        codes = np.array([[get(i, -1) for i in row] for row in seq.tolist()], dtype=np.int32)
         ids, sc, cnt = self.engine.otm_beam_search(codes, beam_size, self.leaf_level)
         out = []
+        n2i = self._node_to_item
         for u in range(ids.shape[0]):
             nodes, scores = ids[u, :cnt[u]], sc[u, :cnt[u]]
-            keep = [(int(self._node_to_item[n]), float(s)) for n, s in zip(nodes, scores)
-                    if 0 <= n < self._node_to_item.size and self._node_to_item[n] >= 0]
-            # stable sort descending by score (sortBy(_.score)(Ordering[Double].reverse))
-            order = sorted(range(len(keep)), key=lambda i: -keep[i][1])
-            out.append([(keep[i][0], float(sigmoid(keep[i][1]))) for i in order[:topk]])
+            items = np.where((nodes >= 0) & (nodes < n2i.size), n2i[np.clip(nodes, 0, n2i.size - 1)], -1)
+            keep = items >= 0                                  # filter(idItemMapping.contains)
+            items, scores = items[keep], scores[keep]
+            order = np.argsort(-scores, kind="stable")[:topk]  # stable sort descending by score (sortBy(_.score)(Ordering[Double].reverse))
+            out.append(list(zip(items[order].tolist(), sigmoid(scores[order]).tolist())))
         return out[0] if single else out
 
 
@@ -106,8 +108,10 @@ class DeepRetrieval:
         single = seq.ndim == 1
         if single:
             seq = seq[None, :]
-        ids = np.array([[self.item_id_mapping.get(int(i), -1) for i in row] for row in seq], dtype=np.int32)   # :32
+        get = self.item_id_mapping.get
+        ids = np.array([[get(i, -1) for i in row] for row in seq.tolist()], dtype=np.int32)   # :32
         out_ids, sc, cnt = self.engine.dr_recommend(ids, beam_size, topk)
-        out = [[(self.id_item_mapping[int(i)], float(sigmoid(s))) for i, s in zip(out_ids[u, :cnt[u]], sc[u, :cnt[u]])]
-               for u in range(ids.shape[0])]
+        back = self.id_item_mapping
+        prob = sigmoid(sc)
+        out = [[(back[i], pr) for i, pr in zip(out_ids[u, :cnt[u]].tolist(), prob[u, :cnt[u]].tolist())] for u in range(ids.shape[0])]
         return out[0] if single else out
