@@ -107,6 +107,16 @@ class JTM:
             self._cached = True
         t_up = time.perf_counter() - t0
         try:
+            if weight_fn is None and self.comm is None and getattr(self, "_cached", False) and os.environ.get("DM_JTM_FUSED", "1") not in ("0", "step"):
+                # single rank: the whole loop over the gap steps in one call, the projection stays on the device between the steps
+                t1 = time.perf_counter()
+                out = np.empty(self.items.size, np.int32)
+                secs = (C.c_double * 2)()
+                self.engine._chk(N.lib().dm_jtm_optimize_cached(self.engine._h, _p(self.item_code, N.i32p), self.items.size, self.max_level, self.gap,
+                                                                int(self.hierarchical), self.min_level, int(self.use_mask), _p(out, N.i32p), secs))
+                if timing is not None:
+                    timing.update(scoring_s=secs[0], rebalance_s=secs[1], host_glue_s=0.0, rows_upload_s=t_up, fused_step_s=time.perf_counter() - t1)
+                return out if as_array else dict(zip(self.items.tolist(), out.tolist()))
             return self._optimize(proj, weight_fn, timing, as_array, t_up)
         finally:
             if getattr(self, "_cached", False):

@@ -294,16 +294,9 @@ class JTM {
     // itemSequenceMap goes to the device once; every gap step is one call (scoring + greedy re-balance, weights stay in HBM)
     e_.check(dm_jtm_cache_rows(e_.handle(), rowOff_.data(), rowIds_.data(), (int64_t)n, L_));
     struct Drop { Engine &e; int L; ~Drop() { dm_jtm_cache_rows(e.handle(), nullptr, nullptr, 0, L); } } drop{e_, L_};
-    for (int oldLevel = 0; oldLevel < maxLevel_; oldLevel += gap_) {
-      const int level = std::min(maxLevel_, oldLevel + gap_);
-      const int maxAssign = 1 << (maxLevel_ - level);              // TreeLearning.scala:56
-      std::vector<int32_t> oldNode(n), next(n);
-      for (size_t i = 0; i < n; i++) oldNode[i] = ancestorAtLevel(itemCode_[i], level);
-      // every parent node of the level in one call; dropped items keep their old node (:72)
-      e_.check(dm_jtm_step_cached(e_.handle(), proj.data(), oldNode.data(), (int64_t)n, oldLevel, level, hier_ ? 1 : 0, minLevel_,
-                                  useMask_ ? 1 : 0, maxAssign, next.data()));
-      proj.swap(next);
-    }
+    // the loop over the gap steps is one call: projection and weights stay in HBM between the steps; dropped items keep their old node (:72)
+    e_.check(dm_jtm_optimize_cached(e_.handle(), itemCode_.data(), (int64_t)n, maxLevel_, gap_, hier_ ? 1 : 0, minLevel_, useMask_ ? 1 : 0,
+                                    proj.data(), nullptr));
     std::map<int32_t, int32_t> res;
     for (size_t i = 0; i < n; i++) res[items_[i]] = proj[i];
     return res;

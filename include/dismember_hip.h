@@ -197,6 +197,12 @@ int dm_jtm_child_weights_cached(dm_handle_t h, const int32_t *item_node, int64_t
  * cached catalogue's size (single-rank runs; sharded runs keep the two separate calls around their all-gather). */
 int dm_jtm_step_cached(dm_handle_t h, const int32_t *item_node, const int32_t *old_node, int64_t n_items, int old_level, int level,
                        int hierarchical, int min_level, int use_mask, int max_assign, int32_t *out_node);
+/* JTM.optimize (JTM.scala:22-73) over the cached catalogue in ONE call: every item starts at the root; each gap step scores the children
+ * chains and re-balances every parent node on the device, and its result feeds the next step without leaving HBM.  item_code [n_items] =
+ * the items' current leaf codes (tree.getAncestorAtLevel is taken from them per step); out_proj [n_items] = every item's new leaf code;
+ * step_seconds (may be NULL) [2] = seconds spent scoring / re-balancing.  Single-rank runs; sharded runs use the per-step calls. */
+int dm_jtm_optimize_cached(dm_handle_t h, const int32_t *item_code, int64_t n_items, int max_level, int gap, int hierarchical, int min_level,
+                           int use_mask, int32_t *out_proj, double *step_seconds);
 /* measurement: seconds the last dm_jtm_step_cached spent in its scoring pass and in its re-balance (copies included) */
 int dm_jtm_last_step_seconds(dm_handle_t h, double *scoring_s, double *rebalance_s);
 /* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable

@@ -18,19 +18,12 @@ class JTM(engine: HipEngine, itemIds: Array[Int], itemCodes: Array[Int], maxLeve
   def optimize(): Map[Int, Int] = {
     val n = itemIds.length
     var node = new Array[Int](n)                                           // every item starts at the root
-    // itemSequenceMap goes to the device once; every gap step is one call (scoring + greedy re-balance, weights stay in HBM)
+    // itemSequenceMap goes to the device once; the loop over the gap steps is one call (scoring + greedy re-balance of every parent node
+    // on the device, projection and weights stay in HBM between the steps)
     Native.jtmCacheRows(engine.handle, rowOff, rowItemIds, n.toLong, seqLen)
     try {
-      var oldLevel = 0
-      while (oldLevel < maxLevel) {
-        val level = math.min(maxLevel, oldLevel + gap)
-        val oldNode = itemCodes.map(ancestorAtLevel(_, level))
-        val out = new Array[Int](n)
-        Native.jtmStepCached(engine.handle, node, oldNode, n.toLong, oldLevel, level, if (hierarchical) 1 else 0, minLevel,
-          if (useMask) 1 else 0, 1 << (maxLevel - level), out)
-        node = out
-        oldLevel = level
-      }
+      Native.jtmOptimizeCached(engine.handle, itemCodes, n.toLong, maxLevel, gap, if (hierarchical) 1 else 0, minLevel,
+        if (useMask) 1 else 0, node, null)
     } finally Native.jtmCacheRows(engine.handle, null, null, 0L, seqLen)
     itemIds.zip(node).toMap
   }

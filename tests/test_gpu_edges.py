@@ -299,8 +299,8 @@ def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
 
 
 def test_jtm_fused_device_steps_equal_separate_host_steps():
-    """JTM.optimize over a 20 000-item catalogue: every gap step as ONE call (dm_jtm_step_cached: scoring, weights kept in HBM,
-    device re-balance) gives the projection of the separate dm_jtm_child_weights_cached + host dm_jtm_rebalance_all calls, and
+    """JTM.optimize over a 20 000-item catalogue: the whole loop as ONE call (dm_jtm_optimize_cached: projection and weights stay in
+    HBM across the gap steps) and every gap step as one call (dm_jtm_step_cached) give the projection of the separate dm_jtm_child_weights_cached + host dm_jtm_rebalance_all calls, and
     it is a bijection onto the leaves (jtm/src/test/scala/JtmSpec.scala:37-51)."""
     from dismember_amd import Engine
     from dismember_amd.jtm import JTM
@@ -318,12 +318,18 @@ def test_jtm_fused_device_steps_equal_separate_host_steps():
     tim = {}
     fused = jt.optimize(as_array=True, timing=tim)
     assert tim["fused_step_s"] > 0 and tim["scoring_s"] > 0 and tim["rebalance_s"] > 0
+    os.environ["DM_JTM_FUSED"] = "step"                        # one call per gap step (dm_jtm_step_cached), the projection through the host
+    try:
+        stepwise = jt.optimize(as_array=True)
+    finally:
+        del os.environ["DM_JTM_FUSED"]
     os.environ["DM_JTM_FUSED"] = "0"; os.environ["DM_JTM_REBALANCE"] = "host"
     try:
         sep = jt.optimize(as_array=True)
     finally:
         del os.environ["DM_JTM_FUSED"], os.environ["DM_JTM_REBALANCE"]
     eng.close()
+    assert np.array_equal(fused, stepwise), int((fused != stepwise).sum())
     assert np.array_equal(fused, sep), int((fused != sep).sum())
     assert np.unique(fused).size == items and fused.min() >= (1 << depth) - 1 and fused.max() <= (1 << (depth + 1)) - 2
 
