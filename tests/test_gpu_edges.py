@@ -418,6 +418,38 @@ def test_adam_step_over_active_rows_equals_dense_stream(dtype):
     assert np.signbit(res["active"][0][6 * E: 7 * E]).all() and not np.signbit(res["active"][0][8 * E: 9 * E]).any()      # untouched signed zeros
 
 
+def test_jtm_cached_entry_points_reject_bad_calls():
+    """dm_jtm_step_cached / dm_jtm_optimize_cached without a cached catalogue, with a catalogue of another size, with impossible
+    levels: an error code and a message, never a launch."""
+    import ctypes as C
+    from dismember_amd import Engine
+    from dismember_amd import _native as N
+    lib = N.lib()
+    rng = np.random.default_rng(8)
+    depth, items, E, L = 9, 300, 32, 10
+    tree = synth.make_tree(items, depth, rng)
+    eng = Engine(0)
+    eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth); eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+    eng.load_weights_din_synthetic(E, (1 << (depth + 1)) - 1, 3, tree_depth=depth, rho=0.9)
+    node = np.zeros(items, np.int32); out = np.empty(items, np.int32); codes = np.sort(tree["leaf_codes"]).astype(np.int32)
+    p = lambda a: a.ctypes.data_as(N.i32p)
+    assert lib.dm_jtm_step_cached(eng._h, p(node), p(node), items, 0, 2, 0, 0, 1, 64, p(out)) == -3            # DM_ERR_STATE: nothing cached
+    assert lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, p(out), None) == -3
+    assert b"dm_jtm_cache_rows" in lib.dm_last_error(eng._h)
+    row_off = np.arange(items + 1, dtype=np.int64)
+    rows = rng.choice(tree["leaf_ids"], (items, L)).astype(np.int32)
+    eng._chk(lib.dm_jtm_cache_rows(eng._h, row_off.ctypes.data_as(N.i64p), p(rows), items, L))
+    assert lib.dm_jtm_step_cached(eng._h, p(node), p(node), items - 1, 0, 2, 0, 0, 1, 64, p(out)) == -1        # another catalogue size
+    assert lib.dm_jtm_step_cached(eng._h, p(node), p(node), items, 2, 2, 0, 0, 1, 64, p(out)) == -1            # level <= old_level
+    assert lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 0, 0, 0, 1, p(out), None) == -1          # gap 0
+    assert lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, None, None) == -1            # no output
+    secs = (C.c_double * 2)()
+    eng._chk(lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, p(out), secs))                # and a good call works
+    assert np.unique(out).size == items and out.min() >= (1 << depth) - 1 and secs[0] > 0
+    eng._chk(lib.dm_jtm_cache_rows(eng._h, None, None, 0, L))
+    eng.close()
+
+
 def test_otm_device_resident_request_equals_host_path():
     """dm_otm_beam_search_dev (request and results in HBM) == dm_otm_beam_search; codes outside the table count as padding."""
     from dismember_amd import Engine
