@@ -64,6 +64,9 @@ def roofline(mode, rows, avg_ms, E, L, kernel=None):
 PEAK_HBM_GBPS = 8000.0
 
 
+_T0 = time.perf_counter()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,11 +227,21 @@ def make_comm(dist, rank, world, local):
     return None, None, err
 
 
+def stage(msg):
+    """Progress on stderr (DM_BENCH_VERBOSE=1): the JSON line on stdout stays the only output the driver parses."""
+    if os.environ.get("DM_BENCH_VERBOSE"):
+        sys.stderr.write("[bench rank %s %.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg)); sys.stderr.flush()
+
+
 def main():
     a = parse()
+    wd = int(os.environ.get("DM_BENCH_WATCHDOG", "0"))
+    if wd > 0:                         # debugging aid: dump every thread's stack and exit if the run is still alive after `wd` seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     from dismember_amd import sharding
     dist, rank, world, local = init_distributed()
-    comm = None
+    comm = comm_transport = comm_err = None
     torch = None
     if dist is not None:
         import torch
@@ -309,6 +322,7 @@ def main():
     cnt = np.empty(U, np.int32)
     eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
 
+    stage("extra the same search with the OTHER scorer arithmetic (same engine, s")
     # ---- extra: the same search with the OTHER scorer arithmetic (same engine, same users) ----
     mode = eng.scorer_mode()["mode"]            # arithmetic in effect for the headline run
     info = eng.scorer_mode()
@@ -405,6 +419,7 @@ def main():
             res["cpu_baseline"]["identical_id_lists"] = "%d/%d" % (same, len(ocnt))
         res_main = res
     default_cfg = (a.items, a.depth) == (10_000_000, 24)
+    stage("extras on the SAME 10M-item engine OTM serving (BASELINE configs[2], c")
     # ---- extras on the SAME 10M-item engine: OTM serving (BASELINE configs[2], complete-tree variant of the level loop) and the
     #      JTM re-assignment scoring step (configs[3]); host-buffer entry points, so these rates include the PCIe copies ----
     otm = jtm = None
@@ -450,6 +465,7 @@ def main():
                            "= %d DIN rows per worker; pairs expanded, scored and summed (reference-order fp32) on the device, host buffers in and out" % (ni_j, ni_j * 4 * 6),
                "items_per_s": world * ni_j / dtj, "din_rows_per_s": world * ni_j * 24 / dtj, "ms": dtj * 1e3,
                "finite_weights": bool(np.isfinite(wj).all())}
+    stage("extra the FULL JTM.optimize over the catalogue (BASELINE configs[3]: e")
     # ---- extra: the FULL JTM.optimize over the catalogue (BASELINE configs[3]: every gap step from the root to the leaves, scoring on
     #      the device, greedy re-balance per parent node), items sharded over the ranks when there are several ----
     jtm_full = None
@@ -459,11 +475,17 @@ def main():
         items_s = tree["leaf_ids"][order]; codes_s = tree["leaf_codes"][order]
         nrow = int(a.jtm_rows)
         t0 = time.perf_counter()
-        hist = seqs[:min(a.users, 262144)]
+        # the catalogue's training rows: the same on every rank (a sharded run splits ONE re-assignment over the ranks)
+        hist = synth.make_users(tree["leaf_ids"], min(a.users, 262144), L, np.random.default_rng(synth.SEED + 78))
         pick = np.random.default_rng(synth.SEED + 77).integers(0, len(hist), size=items_s.size * nrow)
         row_ids = hist[pick].reshape(-1)
         row_off = np.arange(items_s.size + 1, dtype=np.int64) * nrow
-        jtf = JTM.from_arrays(eng, items_s, codes_s, depth, row_off, row_ids, gap=2, seq_len=L, comm=None)
+        jtm_comm, jtm_comm_err = None, None
+        if dist is not None:           # N > 1: ONE JTM.optimize sharded over the ranks inside the library (RCCL all-gathers over xGMI)
+            if comm is None:
+                comm, comm_transport, jtm_comm_err = make_comm(dist, rank, world, local)
+            jtm_comm = comm
+        jtf = JTM.from_arrays(eng, items_s, codes_s, depth, row_off, row_ids, gap=2, seq_len=L, comm=jtm_comm)
         prep = time.perf_counter() - t0
         sync(); barrier()
         tim = {}
@@ -474,15 +496,37 @@ def main():
         first_leaf = (1 << depth) - 1
         steps_j = (depth + 1) // 2
         din_rows = int(items_s.size) * nrow * 6 * steps_j
+        sharded = jtm_comm is not None
+        njobs = 1 if sharded else world            # without a communicator every rank runs the whole re-assignment (replicas)
         jtm_full = {"workload": "JTM.optimize, %d items x %d training rows, depth-%d tree, gap 2: %d gap steps, %d DIN rows scored "
-                                "(6 chain nodes per row and step); every rank runs the whole re-assignment on its own GPU (replicas)"
-                                % (items_s.size, nrow, depth, steps_j, din_rows),
-                    "seconds": dtf, "items_per_s": world * items_s.size / dtf, "din_rows_per_s": world * din_rows / dtf,
+                                "(6 chain nodes per row and step); %s"
+                                % (items_s.size, nrow, depth, steps_j, din_rows,
+                                   ("ONE re-assignment sharded over %d GPUs inside the library (dm_jtm_optimize_cached with a communicator: item-sharded "
+                                    "scoring, in-place all-gather of the weight slices, parent-sharded re-balance + all-gather of the projection)" % world)
+                                   if sharded else ("single GPU" if world == 1 else "every rank runs the whole re-assignment on its own GPU (replicas: no communicator, %s)" % jtm_comm_err)),
+                    "scaling": "strong" if sharded else "weak",
+                    "seconds": dtf, "items_per_s": njobs * items_s.size / dtf, "din_rows_per_s": njobs * din_rows / dtf,
                     "scoring_s": tim.get("scoring_s"), "rebalance_s": tim.get("rebalance_s"), "host_glue_s": tim.get("host_glue_s"),
-                    "rebalance": "on the device (dm_jtm_step_cached: weights stay in HBM)" if tim.get("fused_step_s") else "host",
+                    "rebalance": "on the device (dm_jtm_optimize_cached: weights and projection stay in HBM)" if tim.get("fused_step_s") else "host",
                     "host_preparation_s": prep,
                     "bijection_onto_leaves": bool(np.unique(projf).size == projf.size and int(projf.min()) >= first_leaf)}
+        sh = tim.get("sharding")
+        if sh is not None:
+            # what THIS run did, from the library's own counters (rank 0's view; per-rank item counts differ by at most one)
+            jtm_full["sharding"] = {"rccl_nranks": sh["nranks"] if sh["transport"] == "rccl" else 0, "nranks": sh["nranks"], "transport": sh["transport"],
+                                    "items_scored_by_this_rank_per_step": sh["items_scored"] // steps_j,
+                                    "items_rebalanced_by_this_rank_in_sharded_steps": sh["items_rebalanced_sharded"],
+                                    "steps_replicated_rebalance": sh["steps_replicated_rebalance"], "steps_node_sharded": sh["steps_node_sharded"],
+                                    "weight_bytes_gathered": sh["weight_bytes_gathered"], "projection_bytes_gathered": sh["projection_bytes_gathered"],
+                                    "exchange_ms": sh["exchange_s"] * 1e3}
+        if sharded:
+            import zlib
+            sums = [None] * world
+            dist.all_gather_object(sums, int(zlib.crc32(projf.tobytes())))
+            jtm_full["projection_identical_on_all_ranks"] = bool(len(set(sums)) == 1)
+            eng.attach_comm(None)
         del jtf, row_ids, pick, projf
+    stage("extra BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel ")
     # ---- extra: BASELINE configs[1] (1M-item depth-20 tree) + one data-parallel training step on it ----
     small = train = None
     if a.small and default_cfg:
@@ -536,7 +580,8 @@ def main():
                 small["cpu_baseline"] = base
         comm_note = None
         if a.train and dist is not None:
-            comm, comm_transport, comm_err = make_comm(dist, rank, world, local)
+            if comm is None:
+                comm, comm_transport, comm_err = make_comm(dist, rank, world, local)
             if comm is None:
                 comm_note = "training extra skipped: no communicator (%s)" % comm_err
         if a.train and (dist is None or comm is not None):
@@ -574,6 +619,7 @@ def main():
                                      "host_syncs_per_step": st["host_syncs"], "rows_per_s_per_rank": Tt * per * nts / dtt}
         elif comm_note:
             train = {"skipped": comm_note}
+    stage("extra Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=10")
     # ---- extra: Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=1000, beam=50, 10M items.  The record is the fp64
     #      run (the reference's arithmetic type, deep-retrieval/.../model/LayerModel.scala); the f32 model with the split-fp16
     #      history GEMM is timed beside it on the same inputs ----
@@ -645,6 +691,7 @@ def main():
             dr["cpu_baseline"] = {"value": len(cs) / dtc, "unit": "users/s", "cores": 1, "kind": "port",
                                   "sample": "%d users, fp64 oracle beam search (same D, K, beam, E, L; %d-item catalogue: the work per "
                                             "user does not depend on the catalogue size), 1 thread" % (len(cs), small_items)}
+    stage("extra BASELINE configs[2] in the reference's own arithmetic: the OTM s")
     # ---- extra: BASELINE configs[2] in the reference's own arithmetic: the OTM scorer is DIN[Double] (otm/.../model/DIN.scala:12-39).
     #      fp64 model over the complete depth-24 tree (34.4 GB table), serving on the fused fp64 beam kernel, then ONE
     #      LocalOptimizer iteration (otm/.../optim/LocalOptimizer.scala:55-109): pseudo targets, beam nodes, and per level a
@@ -693,8 +740,20 @@ def main():
                     comm, comm_transport, comm_err = make_comm(dist, rank, world, local)
                 comm6 = comm
             t0 = time.perf_counter()
-            tr6 = OTMTrainer(eng, depth6, a.beam, seq_len=L, lr=1e-4, comm=comm6)
-            sync()
+            tr6, tr6_err = None, None
+            try:
+                tr6 = OTMTrainer(eng, depth6, a.beam, seq_len=L, lr=1e-4, comm=comm6)      # allocates gradient + Adam state: 103 GB more
+                sync()
+            except Exception as ex:      # noqa: BLE001
+                tr6_err = repr(ex)
+            if dist is not None:         # the iteration below is collective: every rank runs it or none does (several ranks squeezed onto
+                oks6 = [None] * world    # one GPU for a smoke test do not fit 2 x 155 GB)
+                dist.all_gather_object(oks6, tr6_err)
+                bad6 = [e_ for e_ in oks6 if e_]
+                if bad6:
+                    raise RuntimeError("fp64 OTM training extra skipped on every rank: a rank could not set up its trainer (%s)" % bad6[0])
+            elif tr6_err:
+                raise RuntimeError(tr6_err)
             t_init6 = time.perf_counter() - t0
             Ut6 = 20                                   # 20 users x 400 candidates = 8000 rows per level (model.total_batch_size 8192)
             tseq6 = oc6[:Ut6]
@@ -716,6 +775,7 @@ def main():
                 "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker"}
         except Exception as ex:
             otm64 = dict(otm64 or {}, error=repr(ex))
+    stage("extra BASELINE configs[0]'s own timer (examples/.../tdm/package.scala:")
     # ---- extra: BASELINE configs[0]'s own timer (examples/.../tdm/package.scala:119-123 prints "Average recommend time"): the bundled
     #      trained E=16 model + tree, one user per call, topk 10, beam 20, 10 warm-up + 100 timed calls through the facade ----
     c1 = None

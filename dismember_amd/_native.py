@@ -68,6 +68,8 @@ SIGNATURES = {
     "dm_jtm_child_weights_cached": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     "dm_jtm_last_step_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dm_jtm_optimize_cached": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double)]),
+    "dm_jtm_optimize_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double)]),
+    "dm_jtm_optimize_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "dm_jtm_step_cached": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]),
     "dm_jtm_rebalance": (C.c_int, [C.c_void_p, f32p, i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]),
     "dm_jtm_rebalance_all": (C.c_int, [C.c_void_p, f32p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p]),

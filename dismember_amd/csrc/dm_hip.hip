@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <thread>
 #include <utility>
@@ -32,6 +33,16 @@
 // ------------------------------------------------------------------ context
 struct dm_dr_state;
 static void dm_dr_free(dm_dr_state *s);
+
+// what the last gradient exchange on a handle moved (comm.hip.inc; dm_train_sync_stats)
+struct dm_sync_stats { uint64_t rows_mine, rows_total, bytes_sent, bytes_recv; int host_syncs, nranks, transport; };
+
+// what the last dm_jtm_optimize_cached on a handle did (jtm_sharded.hip.inc; dm_jtm_optimize_stats)
+struct dm_jtm_stats {
+  int nranks = 1, transport = -1, steps_replicated = 0, steps_node_sharded = 0;
+  uint64_t items_scored = 0, items_rebalanced = 0, weight_bytes = 0, proj_bytes = 0;
+  double scoring_s = 0, rebalance_s = 0, exchange_s = 0;
+};
 
 struct dm_ctx {
   int device = 0;
@@ -123,6 +134,7 @@ struct dm_ctx {
   size_t req_bytes = 0;
   unsigned long long h_rows = 0;
   char *h_stage = nullptr;     // pinned staging block for small host-buffer requests (one upload, one download per call)
+  char *d_stage = nullptr;     // the same block as the kernels address it (hipHostGetDevicePointer): single-request path
   size_t stage_bytes = 0;
   // cached search workspace
   void *d_ws = nullptr;
@@ -142,6 +154,8 @@ struct dm_ctx {
   std::vector<int64_t> jtm_off;
   int jtm_L = 0;
   struct dm_comm *comm = nullptr;
+  dm_sync_stats sync_stats{};
+  dm_jtm_stats jtm_stats{};
   void *d_sync = nullptr;
   size_t sync_bytes = 0;
 };
@@ -273,6 +287,24 @@ static int dm_alloc(dm_ctx *h, void **p, size_t bytes) {
     if (rc_ != DM_OK) return rc_;                              \
   } while (0)
 static void dm_free_ptr(void *p) { if (p) (void)hipFree(p); }
+
+// The 256 KB pinned staging block of the small-request paths.  It is also what the single-request kernels read and write in place
+// and whose count words the host polls, so it is allocated COHERENT explicitly (fine-grained: device stores become visible to the
+// host without a kernel boundary) and the kernels get the address hipHostGetDevicePointer reports, not the host pointer.
+static int ensure_stage(dm_ctx *h) {
+  if (h->h_stage && h->stage_bytes >= (256u << 10)) return DM_OK;
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  h->h_stage = nullptr; h->d_stage = nullptr; h->stage_bytes = 0;
+  if (hipHostMalloc((void **)&h->h_stage, 256u << 10, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess)
+    return fail(h, DM_ERR_HIP, "hipHostMalloc failed");
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, h->h_stage, 0) != hipSuccess || !dp) {
+    (void)hipHostFree(h->h_stage); h->h_stage = nullptr;
+    return fail(h, DM_ERR_HIP, "hipHostGetDevicePointer failed");
+  }
+  h->d_stage = (char *)dp; h->stage_bytes = 256u << 10;
+  return DM_OK;
+}
 
 // Mask.scala:10 — scale = 1 / sqrt(embedSize) of the model as loaded (zero padding of the table does not change it)
 static double sm_scale64(const dm_ctx *h) { return 1.0 / sqrt((double)(h->embed_log > 0 ? h->embed_log : h->embed)); }
@@ -1186,6 +1218,9 @@ static int ensure_split(dm_ctx *h) {
 
 static int ensure_f32_mirror(dm_ctx *h);
 static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
+  // the host-polled epilogue (results, system-scope fence, count as the flag) exists for the TDM final selection only: the mode-1 (OTM)
+  // epilogue stores its counts before the ids and without a fence
+  if (p.host_direct && p.mode != 0) return fail(h, DM_ERR_STATE, "launch_beam: the host-mapped single-request path is a mode-0 (TDM) path");
   {   // f64 model trained since the f32 copies were made: refresh them (and the scorer parameters fill_common took from them)
     const bool was = h->f32_mirror_dirty;
     int rc_ = ensure_f32_mirror(h);
@@ -1410,12 +1445,7 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
     // through ONE pinned staging block — a pageable copy costs 10-15 us each, and a single-user search is 60 us of kernel
     const size_t down = 2 * b_out + b_cnt;
     const bool staged = !coff && !tn && b_seq + down <= (256u << 10);
-    if (staged && h->stage_bytes < b_seq + down) {
-      if (h->h_stage) (void)hipHostFree(h->h_stage);
-      h->h_stage = nullptr; h->stage_bytes = 0;
-      if (hipHostMalloc((void **)&h->h_stage, 256u << 10, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "hipHostMalloc failed"); break; }
-      h->stage_bytes = 256u << 10;
-    }
+    if (staged && (rc = ensure_stage(h)) != DM_OK) break;
     if (staged) memcpy(h->h_stage, seq, (size_t)U * L * 4);
     if (staged && h->direct_ok && U <= 8) {
       // Single-request path (the reference's serving loop: one user per call, examples/.../tdm/package.scala:114-124).  The staging
@@ -1425,8 +1455,8 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
       volatile int32_t *m_cnt = (volatile int32_t *)(h->h_stage + b_seq + 2 * b_out);
       for (int64_t u = 0; u < U; u++) m_cnt[u] = -1;
       bool direct = true;
-      rc = tdm_search_dev(h, (const int32_t *)h->h_stage, U, L, opts, mb, nullptr, nullptr, m_ids, m_sc, (int32_t *)m_cnt, 0, nullptr, nullptr,
-                          nullptr, &direct);
+      rc = tdm_search_dev(h, (const int32_t *)h->d_stage, U, L, opts, mb, nullptr, nullptr, (int32_t *)(h->d_stage + b_seq),
+                          (float *)(h->d_stage + b_seq + b_out), (int32_t *)(h->d_stage + b_seq + 2 * b_out), 0, nullptr, nullptr, nullptr, &direct);
       if (rc != DM_OK) break;
       if (direct) {
         bool done = false;
@@ -1728,6 +1758,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "dr_host.hip.inc"
 #include "otm64.hip.inc"
 #include "comm.hip.inc"
+#include "jtm_sharded.hip.inc"
 #include "checkpoint.hip.inc"
 
 // ---- device memory helpers

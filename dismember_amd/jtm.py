@@ -1,9 +1,13 @@
 """JTM tree learning: mirror of com.mass.jtm.optim.JTM (jtm/src/main/scala/com/mass/jtm/optim/JTM.scala:8-73).
 
 `JTM(...).optimize()` returns the new projection item id -> leaf code, like the reference's
-`Map[Int, Int]`.  Scoring (TreeLearning.aggregateWeights) runs on the GPU through dm_jtm_child_weights;
-the greedy re-balance is the exact host logic of dm_jtm_rebalance.  Items are iterated in ascending id
-(the reference iterates a Scala HashMap — only relevant for ties).
+`Map[Int, Int]`.  The whole loop over the gap steps is ONE library call (dm_jtm_optimize_cached): scoring
+(TreeLearning.aggregateWeights), the greedy re-balance of every parent node and the projection stay in HBM.
+With `comm` (dismember_amd.comm.Comm: one rank per GPU) the same call is collective and sharded like the
+reference's workers (JTM.scala:33-68): item-sharded scoring, the weight slices all-gathered device to device,
+the re-balance sharded by parent node once a level has as many parents as ranks — bit-identical to one rank.
+Items are iterated in ascending id (the reference iterates a Scala HashMap — only relevant for ties, see
+DESIGN.md).
 """
 import ctypes as C
 
@@ -107,21 +111,36 @@ class JTM:
             self._cached = True
         t_up = time.perf_counter() - t0
         try:
-            if weight_fn is None and self.comm is None and getattr(self, "_cached", False) and os.environ.get("DM_JTM_FUSED", "1") not in ("0", "step"):
-                # single rank: the whole loop over the gap steps in one call, the projection stays on the device between the steps
+            lib_comm = self.comm is None or hasattr(self.comm, "_c")     # None, or the library's own communicator (not a test adapter)
+            if weight_fn is None and lib_comm and getattr(self, "_cached", False) and os.environ.get("DM_JTM_FUSED", "1") not in ("0", "step"):
+                # the whole loop over the gap steps in one call, the projection stays on the device between the steps; with a
+                # communicator the call is collective: sharded scoring / re-balance, RCCL all-gathers inside the library
+                if self.comm is not None:
+                    self.engine.attach_comm(self.comm)
                 t1 = time.perf_counter()
                 out = np.empty(self.items.size, np.int32)
                 secs = (C.c_double * 2)()
                 self.engine._chk(N.lib().dm_jtm_optimize_cached(self.engine._h, _p(self.item_code, N.i32p), self.items.size, self.max_level, self.gap,
                                                                 int(self.hierarchical), self.min_level, int(self.use_mask), _p(out, N.i32p), secs))
                 if timing is not None:
-                    timing.update(scoring_s=secs[0], rebalance_s=secs[1], host_glue_s=0.0, rows_upload_s=t_up, fused_step_s=time.perf_counter() - t1)
+                    timing.update(scoring_s=secs[0], rebalance_s=secs[1], host_glue_s=0.0, rows_upload_s=t_up, fused_step_s=time.perf_counter() - t1,
+                                  sharding=self.optimize_stats())
                 return out if as_array else dict(zip(self.items.tolist(), out.tolist()))
             return self._optimize(proj, weight_fn, timing, as_array, t_up)
         finally:
             if getattr(self, "_cached", False):
                 self._cached = False
                 self.engine._chk(N.lib().dm_jtm_cache_rows(self.engine._h, None, None, 0, self.L))
+
+    def optimize_stats(self):
+        """dm_jtm_optimize_stats of the last fused optimize on this engine: ranks, transport, items this rank scored / re-balanced,
+        replicated and node-sharded steps, bytes all-gathered, seconds in scoring / re-balance / exchange."""
+        o = (C.c_uint64 * 10)(); t = (C.c_double * 3)()
+        self.engine._chk(N.lib().dm_jtm_optimize_stats(self.engine._h, o, t))
+        tr = {0: "host", 1: "rccl"}.get(int(o[1]) if o[1] < 2 else -1, "none")
+        return {"nranks": int(o[0]), "transport": tr, "items_scored": int(o[2]), "items_rebalanced_sharded": int(o[3]),
+                "steps_replicated_rebalance": int(o[4]), "steps_node_sharded": int(o[5]), "weight_bytes_gathered": int(o[6]),
+                "projection_bytes_gathered": int(o[7]), "scoring_s": t[0], "rebalance_s": t[1], "exchange_s": t[2]}
 
     def _optimize(self, proj, weight_fn, timing, as_array, t_up):
         import time

@@ -200,9 +200,25 @@ int dm_jtm_step_cached(dm_handle_t h, const int32_t *item_node, const int32_t *o
 /* JTM.optimize (JTM.scala:22-73) over the cached catalogue in ONE call: every item starts at the root; each gap step scores the children
  * chains and re-balances every parent node on the device, and its result feeds the next step without leaving HBM.  item_code [n_items] =
  * the items' current leaf codes (tree.getAncestorAtLevel is taken from them per step); out_proj [n_items] = every item's new leaf code;
- * step_seconds (may be NULL) [2] = seconds spent scoring / re-balancing.  Single-rank runs; sharded runs use the per-step calls. */
+ * step_seconds (may be NULL) [2] = seconds spent scoring / re-balancing.
+ * With a communicator attached (dm_comm_attach, > 1 rank) the call is COLLECTIVE and the run is sharded the way the reference's workers
+ * split it (JTM.scala:33-68, JTMAsync.scala:43-75): every rank holds the cached catalogue and scores the rows of ITS contiguous item range
+ * (sizes as taskSize / extraSize, :47-52); the [items x 2^gap] weight slices are all-gathered in place, device to device (RCCL over xGMI;
+ * host staging on DM_COMM_HOST); the greedy re-balance runs replicated while a level has fewer parent nodes than ranks and afterwards
+ * over each rank's contiguous range of parent nodes, followed by an all-gather of (item, new node) pairs.  Each weight is one GPU's
+ * sequential fp32 sum and each parent's list keeps item order, so out_proj is bit-identical to the single-rank result on every rank. */
 int dm_jtm_optimize_cached(dm_handle_t h, const int32_t *item_code, int64_t n_items, int max_level, int gap, int hierarchical, int min_level,
                            int use_mask, int32_t *out_proj, double *step_seconds);
+/* the same from ONE process driving all ranks of a dm_comm_create_all clique (the reference's shape: one JVM, numThreads workers):
+ * hs[i] carries rank i and its own cached catalogue; ranks run on host threads of this call.  The ranks' projections are compared
+ * (DM_ERR_STATE if they differ) and out_proj receives the common one.  n == 1 is dm_jtm_optimize_cached. */
+int dm_jtm_optimize_all(dm_handle_t *hs, int n, const int32_t *item_code, int64_t n_items, int max_level, int gap, int hierarchical,
+                        int min_level, int use_mask, int32_t *out_proj, double *step_seconds);
+/* measurement — what the last dm_jtm_optimize_cached on this handle did: out10[0..9] = ranks, transport (DM_COMM_*; 2^64-1 = no
+ * communicator), items this rank scored summed over the gap steps, items it re-balanced in node-sharded steps, steps with a replicated
+ * re-balance, node-sharded steps, weight bytes all-gathered, projection bytes all-gathered, 0, 0; secs3 = scoring, re-balance,
+ * exchange seconds. */
+int dm_jtm_optimize_stats(dm_handle_t h, uint64_t *out10, double *secs3);
 /* measurement: seconds the last dm_jtm_step_cached spent in its scoring pass and in its re-balance (copies included) */
 int dm_jtm_last_step_seconds(dm_handle_t h, double *scoring_s, double *rebalance_s);
 /* getChildrenProjection after scoring (:58-97) for the items of ONE parent `node`: sortNodeWeights (stable
@@ -279,7 +295,7 @@ int dm_train_add_rows(dm_handle_t h, const int32_t *d_rows, const void *d_grads,
  * reduction order, not rank order; the HOST transport sums in rank order).  RCCL transport: one ncclAllGather of 16-byte
  * {count, ok} records + ONE host read-back, then one ncclAllReduce and one ncclAllGather of max-padded row blocks.
  * Collective: every rank must call it; a rank whose touched-row list overflowed makes EVERY rank return DM_ERR_STATE.
- * dm_train_sync_stats: what the last exchange of this process moved — out[0..7] = nranks, transport, touched rows of this
+ * dm_train_sync_stats: what the last exchange on this handle moved — out[0..7] = nranks, transport, touched rows of this
  * rank, touched rows of all ranks, bytes sent, bytes received, host synchronisations, 0. */
 typedef struct dm_comm *dm_comm_t;
 enum { DM_COMM_HOST = 0, DM_COMM_RCCL = 1 };

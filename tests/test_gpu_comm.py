@@ -200,3 +200,134 @@ def test_clique_all_devices_replicas_identical():
     dense = np.sum([g[NI * E:].astype(np.float64) for g in local], axis=0)
     assert np.allclose(summed[0][NI * E:], dense, rtol=1e-5, atol=1e-7)
     assert st["nranks"] == len(devs) and st["transport"] == "rccl" and st["host_syncs"] == 2
+
+
+# --------------------------------------------------------------------------- sharded JTM.optimize (BASELINE configs[3])
+def _jtm_setup(items=20_000, depth=15, E=32, L=10, nrow=3, device=0):
+    """The same engine + JTM problem on every worker (deterministic seeds): replicated table, the catalogue's rows cached per rank."""
+    from dismember_amd import Engine, synth
+    from dismember_amd.jtm import JTM
+    rng = np.random.default_rng(5)
+    tree = synth.make_tree(items, depth, rng)
+    eng = Engine(device)
+    eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth); eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+    eng.load_weights_din_synthetic(E, (1 << (depth + 1)) - 1, 11, tree_depth=depth, rho=0.9)
+    hist = synth.make_users(tree["leaf_ids"], 4096, L, np.random.default_rng(1))
+    order = np.argsort(tree["leaf_ids"], kind="stable")
+    nr = np.random.default_rng(3).integers(0, 2 * nrow + 1, size=items)              # ragged: 0 .. 2 nrow training rows per item
+    off = np.concatenate([[0], np.cumsum(nr)]).astype(np.int64)
+    pick = np.random.default_rng(2).integers(0, len(hist), size=int(off[-1]))
+    jt = JTM.from_arrays(eng, tree["leaf_ids"][order], tree["leaf_codes"][order], depth, off, hist[pick].reshape(-1), gap=2, seq_len=L)
+    return eng, jt
+
+
+def _jtm_worker(rank, world, port, q, items):
+    from dismember_amd.comm import Comm
+    eng, jt = _jtm_setup(items=items)
+    single = jt.optimize(as_array=True) if rank == 0 else None          # rank 0 also runs it alone first (no communicator yet)
+    comm = Comm(world, rank, "127.0.0.1", port, transport="host")
+    jt.comm = comm
+    tim = {}
+    proj = jt.optimize(as_array=True, timing=tim)
+    q.put((rank, proj, single, tim["sharding"]))
+    comm.barrier()
+    eng.attach_comm(None)
+    eng.close(); comm.close()
+
+
+@pytest.mark.parametrize("world,items", [(2, 20_000), (3, 20_001)])
+def test_jtm_sharded_optimize_equals_single_rank(world, items):
+    """JTM.optimize sharded over W workers inside the library (JTM.scala:33-68: items of a node split while a level has fewer parents
+    than workers, contiguous parent-node ranges afterwards): every rank ends with the projection a single rank computes, bit for bit.
+    W processes share the one GPU over the host transport; on RCCL only the wire differs."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_jtm_worker, args=(r, world, port, q, items)) for r in range(world)]
+    [p.start() for p in procs]
+    out = sorted((q.get(timeout=900) for _ in range(world)), key=lambda t: t[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    single = out[0][2]
+    depth, gap = 15, 2
+    assert np.unique(single).size == items and single.min() >= (1 << depth) - 1 and single.max() <= (1 << (depth + 1)) - 2
+    steps = -(-depth // gap)
+    scored = 0
+    for r in range(world):
+        st = out[r][3]
+        assert np.array_equal(out[r][1], single), (r, int((out[r][1] != single).sum()))
+        assert st["nranks"] == world and st["transport"] == "host"
+        # fewer parents than workers only at the root (1 parent) and — three workers — nowhere else: 4 >= 3
+        assert st["steps_replicated_rebalance"] == 1 and st["steps_node_sharded"] == steps - 1
+        base, rem = divmod(items, world)
+        assert st["items_scored"] == steps * (base + (1 if r < rem else 0))          # its contiguous item range, every step
+        assert st["weight_bytes_gathered"] == (steps - 1) * items * 4 * 4 + items * (1 << (depth - (steps - 1) * gap)) * 4
+        assert st["projection_bytes_gathered"] == (steps - 1) * items * 8               # (item, node) pairs of every item, every sharded step
+        scored += st["items_rebalanced_sharded"]
+    assert scored == (steps - 1) * items                                               # every item re-balanced by exactly one rank per step
+
+
+def test_jtm_optimize_overfull_catalogue_device_equals_host():
+    """More items than leaves (the catalogue exceeds 2^max_level): the greedy loop drops items, which then sit in a node ABOVE the next
+    step's parents.  The reference skips them (JTM.scala:36 visits getAllNodesAtLevel(oldLevel) only; `oldProjection ++ new` keeps
+    their entry); so do the device rounds and the host logic — identically."""
+    eng, jt = _jtm_setup(items=20_000, depth=15)
+    jt.max_level = 14                                              # learn a 14-level tree: 16 384 leaves for 20 000 items
+    fused = jt.optimize(as_array=True)
+    os.environ["DM_JTM_FUSED"] = "0"; os.environ["DM_JTM_REBALANCE"] = "host"
+    try:
+        sep = jt.optimize(as_array=True)
+    finally:
+        del os.environ["DM_JTM_FUSED"], os.environ["DM_JTM_REBALANCE"]
+    eng.close()
+    assert np.array_equal(fused, sep), int((fused != sep).sum())
+    lv = np.frexp(fused.astype(np.float64) + 1)[1] - 1
+    assert (lv < 14).sum() >= 20_000 - 16_384 and (lv == 14).sum() <= 16_384          # the dropped items stayed above the leaf level
+    leaves = fused[lv == 14]
+    assert np.unique(leaves).size == leaves.size                                       # capacity 1 per leaf
+
+
+def _clique_jtm(devices):
+    import ctypes as C
+    from dismember_amd import _native as N
+    from dismember_amd.comm import make_clique
+    from dismember_amd.engine import _p
+    comms = make_clique(devices)
+    engs, jts = [], []
+    for i, d in enumerate(devices):
+        e, jt = _jtm_setup(device=d)
+        engs.append(e); jts.append(jt)
+    single = jts[0].optimize(as_array=True)
+    for i, (e, jt) in enumerate(zip(engs, jts)):
+        e.attach_comm(comms[i])
+        e._chk(N.lib().dm_jtm_cache_rows(e._h, _p(jt.row_off, N.i64p), _p(jt.row_ids, N.i32p), jt.items.size, jt.L))
+    hs = (C.c_void_p * len(engs))(*[e._h for e in engs])
+    out = np.empty(jts[0].items.size, np.int32)
+    rc = N.lib().dm_jtm_optimize_all(hs, len(engs), _p(jts[0].item_code, N.i32p), out.size, jts[0].max_level, 2, 0, 0, 1, _p(out, N.i32p), None)
+    assert rc == 0, N.lib().dm_last_error(engs[0]._h)
+    stats = [jt.optimize_stats() for jt in jts]
+    for e in engs:
+        e.attach_comm(None); e.close()
+    for c in comms:
+        N.lib().dm_comm_destroy(c)
+    return single, out, stats
+
+
+def test_clique_single_device_jtm_optimize_all():
+    single, out, stats = _clique_jtm([0])
+    assert np.array_equal(single, out) and stats[0]["nranks"] == 1 and stats[0]["steps_node_sharded"] == 0
+
+
+def test_clique_all_devices_jtm_optimize():
+    """Every GPU of the box in one process (skipped on one-GPU boxes): dm_jtm_optimize_all over RCCL — item-sharded scoring, in-place
+    ncclBroadcast all-gather of the weight slices, parent-sharded re-balance — equals the single-GPU projection."""
+    from dismember_amd import _native as N
+    import ctypes as C
+    n = C.c_int(0)
+    N.lib().dm_device_count(C.byref(n))
+    if n.value < 2:
+        pytest.skip("needs >= 2 GPUs in one process (dm_comm_create_all); this box has %d" % n.value)
+    devs = list(range(min(n.value, 4)))
+    single, out, stats = _clique_jtm(devs)
+    assert np.array_equal(single, out)
+    assert all(s["nranks"] == len(devs) and s["transport"] == "rccl" and s["steps_node_sharded"] > 0 for s in stats)

@@ -593,6 +593,59 @@ def test_checkpoint_save_load_identical_recommendations(tmp_path):
         e4.load_model(bad)
     e4.close()
 
+def test_checkpoint_corrupt_files_leave_the_handle_untouched(tmp_path):
+    """A corrupt or truncated checkpoint returns DM_ERR_INVALID (no exception escapes the C ABI: under JNI that would abort the JVM)
+    and leaves tree, id maps and weights of the handle exactly as they were; a save that fails keeps the previous file."""
+    import struct
+    from dismember_amd import DismemberError, Engine
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    t = np.load(os.path.join(g, "tdm_tree.npz")); w = np.load(os.path.join(g, "din_f32.npy"))
+    rng = np.random.default_rng(9)
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(w, 16, 8191)
+    users = random_histories(rng, t["leaf_ids"], 16, 10)
+    before = eng.tdm_beam_search(users, 20, 10)
+    good = str(tmp_path / "good.ck")
+    eng.save_model(good)
+    assert not os.path.exists(good + ".tmp")
+    raw = open(good, "rb").read()
+    hdr = struct.Struct("<8s8i4q")
+    f = list(hdr.unpack_from(raw))
+    # field indices: 1 version, 2 dtype, 3 embed, 4 max_level, 5 has_tree, 6 has_ids, 9 num_index, 10 n_elems, 11 n_nodes, 12 n_leaf_ids
+
+    def variant(**kw):
+        g_ = list(f)
+        for k, v in kw.items():
+            g_[{"embed": 3, "max_level": 4, "num_index": 9, "n_elems": 10, "n_nodes": 11, "n_leaf_ids": 12, "dtype": 2}[k]] = v
+        return hdr.pack(*g_) + raw[hdr.size:]
+    cases = {
+        "huge_n_nodes": variant(n_nodes=1 << 60),               # would size a std::vector from 2^60
+        "negative_leaf_ids": variant(n_leaf_ids=-5),
+        "huge_num_index": variant(num_index=(1 << 62) // 16, n_elems=((1 << 62) // 16) * 16 + 3 * 256 + 33),   # num_index * E overflows
+        "embed_0": variant(embed=0), "embed_4096": variant(embed=4096), "max_level_99": variant(max_level=99), "dtype_7": variant(dtype=7),
+        "truncated_in_weights": raw[:len(raw) - 1000],
+        "truncated_in_tree": raw[:hdr.size + 100],
+        "trailing_bytes": raw + b"x" * 8,
+        "bad_tree_code": raw[:hdr.size] + struct.pack("<i", -3) + raw[hdr.size + 4:],
+    }
+    for name, blob in cases.items():
+        path = str(tmp_path / (name + ".ck"))
+        open(path, "wb").write(blob)
+        with pytest.raises(DismemberError) as e:
+            eng.load_model(path)
+        assert e.value.code == -1, (name, e.value.code)
+        after = eng.tdm_beam_search(users, 20, 10)               # tree, id maps and weights are still the old ones
+        assert all(np.array_equal(a, b) for a, b in zip(before, after)), name
+    # a save into a directory that does not exist fails and does not disturb an existing checkpoint
+    with pytest.raises(DismemberError):
+        eng.save_model(str(tmp_path / "no_such_dir" / "m.ck"))
+    assert open(good, "rb").read() == raw
+    eng.save_model(good)                                         # overwrite in place: through good.ck.tmp + rename
+    assert open(good, "rb").read() == raw and not os.path.exists(good + ".tmp")
+    eng.close()
+
+
 
 @pytest.mark.parametrize("E,dtype", [(24, np.float32), (48, np.float32), (100, np.float32), (80, np.float64), (8, np.float64)])
 def test_embed_sizes_the_kernels_pad(oracle, tmp_path, E, dtype):

@@ -53,9 +53,11 @@ VOID_HOST = {
 FIXED = {("dm_load_weights_din", "F32"): {"dtype": "DM_F32"}, ("dm_load_weights_din", "F64"): {"dtype": "DM_F64"}}   # args the variant pins
 HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: written out below
 # entry points that neither wait on peers / the network nor run a long device job: the only ones allowed a Critical region
-CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_memcpy_h2d", "dm_memcpy_d2h", "dm_kernel_timing_get",
+# (not dm_create — HIP runtime and device initialisation can take seconds — and not dm_memcpy_h2d / _d2h: arbitrarily large
+# synchronous copies; both would hold the GC locker for their whole duration)
+CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_kernel_timing_get",
                "dm_kernel_timing_get_kind", "dm_get_scorer_mode", "dm_comm_rank", "dm_device_count", "dm_last_scored_rows",
-               "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_adam_last_step_rows", "dm_comm_unique_id", "dm_dev_alloc", "dm_create"}
+               "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_adam_last_step_rows", "dm_comm_unique_id", "dm_dev_alloc"}
 JTYPE = {"jint": "Int", "jlong": "Long", "jfloat": "Float", "jdouble": "Double", "jbyte": "Byte"}
 
 
@@ -114,6 +116,7 @@ def gen(protos):
     c, sc = [], []
     for meth, cname, ret, args, voids in expand(protos):
         jparams, sparams, pre, post, call = [], [], [], [], []
+        pinned = []            # host arrays acquired from the JVM: a NULL for a non-null array means a pending OutOfMemoryError
         handle_expr, comm_expr = "0", None
         for i, a in enumerate(args):
             base, ptr, an, const = a["base"], a["ptr"], a["name"], a["const"]
@@ -129,7 +132,7 @@ def gen(protos):
             elif base in ("dm_handle_t", "dm_comm_t") and ptr == "*":      # out handle(s) or a list of handles
                 jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
                 a_, r_ = pin(cname, "jlong", an, False)
-                pre.append(a_); post.append(r_)
+                pre.append(a_); post.append(r_); pinned.append(an)
                 call.append("(%s *)p_%s" % (base, an))
             elif base in STRUCTS and ptr == "*":
                 fields = STRUCTS[base]
@@ -140,19 +143,19 @@ def gen(protos):
             elif base == "char" and ptr == "*":
                 jparams.append("jstring %s" % an); sparams.append("%s: String" % an)
                 pre.append("  const char *p_%s = %s ? (*e)->GetStringUTFChars(e, %s, 0) : 0;" % (an, an, an))
-                post.append("  if (p_%s) (*e)->ReleaseStringUTFChars(e, %s, p_%s);" % (an, an, an))
+                post.append("  if (p_%s) (*e)->ReleaseStringUTFChars(e, %s, p_%s);" % (an, an, an)); pinned.append(an)
                 call.append("p_%s" % an)
             elif base == "void" and ptr == "*" and an in voids:               # host buffer of a known element type
                 jt, je, st = ARRAY[voids[an]]
                 jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
                 a_, r_ = pin(cname, je, an, const)
-                pre.append(a_); post.append(r_)
+                pre.append(a_); post.append(r_); pinned.append(an)
                 call.append("p_%s" % an)
             elif ptr in ("*", "**") and (base == "void" or an.startswith("d_") or an == "dptr"):   # device pointers travel as jlong
                 if ptr == "**" or (base != "void" and an in ("d_ptr",)) or an == "dptr":
                     jparams.append("jlongArray %s" % an); sparams.append("%s: Array[Long]" % an)
                     a_, r_ = pin(cname, "jlong", an, False)
-                    pre.append(a_); post.append(r_)
+                    pre.append(a_); post.append(r_); pinned.append(an)
                     call.append("(%s %s)p_%s" % (base, ptr, an))
                 else:
                     jparams.append("jlong %s" % an); sparams.append("%s: Long" % an)
@@ -161,7 +164,7 @@ def gen(protos):
                 jt, je, st = ARRAY[base]
                 jparams.append("%s %s" % (jt, an)); sparams.append("%s: %s" % (an, st))
                 a_, r_ = pin(cname, je, an, const)
-                pre.append(a_); post.append(r_)
+                pre.append(a_); post.append(r_); pinned.append(an)
                 call.append("(%s%s *)p_%s" % ("const " if const else "", base, an))
             elif ptr == "" and base in SCALAR:
                 jparams.append("%s %s" % (SCALAR[base][0], an)); sparams.append("%s: %s" % (an, SCALAR[base][1]))
@@ -171,6 +174,13 @@ def gen(protos):
         jret, sret = ("jstring", "String") if ret != "int" else (("jint", "Int") if cname in ("dm_version",) else ("void", "Unit"))
         sig = "JNIEXPORT %s JNICALL Java_com_mass_hip_Native_%s(JNIEnv *e, jclass cls%s) {" % (jret, meth.replace("_", "_1"), "".join(", " + p for p in jparams))
         body = [sig] + pre
+        if pinned:
+            # the JVM could not hand out one of the arrays (an exception is already pending): give back what was acquired and
+            # return to Java without calling into the library or throwing on top of it
+            body.append("  if (%s) {" % " || ".join("(%s && !p_%s)" % (an, an) for an in pinned))
+            body += ["  " + ln.replace(", 0);", ", JNI_ABORT);") for ln in post[::-1]]      # nothing was written: no copy-back
+            body.append("    (void)cls; return%s;" % (" 0" if ret != "int" or cname in ("dm_version",) else ""))
+            body.append("  }")
         callexpr = "%s(%s)" % (cname, ", ".join(call))
         if ret != "int":
             body.append("  const char *r_ = %s;" % callexpr)

@@ -26,7 +26,7 @@ proj = jt.optimize(timing=tim, as_array=True)
 dt = time.perf_counter() - t0
 print("JTM.optimize: %d items, depth %d, %d gap steps: %.2f s  (%.0f items/s); bijection onto leaves: %s; split %s" %
       (items, depth, (depth + 1) // 2, dt, items / dt, np.unique(proj).size == items and int(proj.min()) >= (1 << depth) - 1,
-       {k: round(v, 2) for k, v in tim.items()}))
+       {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tim.items()}))
 tw = tr = 0.0
 proj = np.zeros(jt.items.size, np.int32)
 eng._chk(N.lib().dm_jtm_cache_rows(eng._h, jt.row_off.ctypes.data_as(N.i64p), jt.row_ids.ctypes.data_as(N.i32p), jt.items.size, L)); jt._cached = True
