@@ -120,6 +120,8 @@ class Engine {
   }
   int maxLevel() const { return maxLevel_; }
   int embedSize() const { return embed_; }
+  // multi-GPU: the communicator this engine's collectives use (dm_comm_create_tcp / _rccl / _all); not owned, nullptr detaches
+  void attachComm(dm_comm_t c) { check(dm_comm_attach(h_, c)); }
 
  private:
   dm_handle_t h_ = nullptr;
@@ -257,7 +259,10 @@ struct Metrics {
   }
 };
 
-// JTM tree learning: JTM.optimize (JTM.scala:22-73) over dm_jtm_child_weights + dm_jtm_rebalance.
+// JTM tree learning: JTM.optimize (JTM.scala:22-73) as one library call (dm_jtm_optimize_cached).  The reference's `numThreads`
+// workers (JTM.scala:33-68) are GPUs here: attach a communicator to the engine (Engine::attachComm: one process per GPU, every process
+// constructs the same JTM and calls optimize() — collective), or hand optimizeAll() the engines of one process driving several GPUs
+// (dm_comm_create_all clique); both give the single-GPU projection bit for bit.
 class JTM {
  public:
   // leafItemIds / leafCodes: the CURRENT tree's item -> leaf code map; itemRows[item] = flattened [rows x seqLen] histories
@@ -297,6 +302,20 @@ class JTM {
     // the loop over the gap steps is one call: projection and weights stay in HBM between the steps; dropped items keep their old node (:72)
     e_.check(dm_jtm_optimize_cached(e_.handle(), itemCode_.data(), (int64_t)n, maxLevel_, gap_, hier_ ? 1 : 0, minLevel_, useMask_ ? 1 : 0,
                                     proj.data(), nullptr));
+    std::map<int32_t, int32_t> res;
+    for (size_t i = 0; i < n; i++) res[items_[i]] = proj[i];
+    return res;
+  }
+  // one process, several GPUs: engines[i] carries rank i of a dm_comm_create_all clique (engines[0] may be this object's engine);
+  // every engine gets the catalogue's rows, the ranks run on host threads inside the call and must end with the same projection
+  std::map<int32_t, int32_t> optimizeAll(const std::vector<Engine *> &engines) {
+    const size_t n = items_.size();
+    std::vector<int32_t> proj(n, 0);
+    std::vector<dm_handle_t> hs;
+    for (Engine *e : engines) { e->check(dm_jtm_cache_rows(e->handle(), rowOff_.data(), rowIds_.data(), (int64_t)n, L_)); hs.push_back(e->handle()); }
+    struct Drop { const std::vector<Engine *> &es; int L; ~Drop() { for (Engine *e : es) dm_jtm_cache_rows(e->handle(), nullptr, nullptr, 0, L); } } drop{engines, L_};
+    engines.at(0)->check(dm_jtm_optimize_all(hs.data(), (int)hs.size(), itemCode_.data(), (int64_t)n, maxLevel_, gap_, hier_ ? 1 : 0, minLevel_,
+                                             useMask_ ? 1 : 0, proj.data(), nullptr));
     std::map<int32_t, int32_t> res;
     for (size_t i = 0; i < n; i++) res[items_[i]] = proj[i];
     return res;

@@ -1,30 +1,37 @@
-// JTM.scala — JTM.optimize(): Map[Int, Int] (jtm/src/main/scala/com/mass/jtm/optim/JTM.scala:22-73): per gap step the child
-// weights of every item on the device (TreeLearning.aggregateWeights, jtm/.../optim/TreeLearning.scala:152-174) and the exact
-// greedy re-balance of every parent node (:217-265) in one call each.
+// JTM.scala — JTM.optimize(): Map[Int, Int] (jtm/src/main/scala/com/mass/jtm/optim/JTM.scala:22-73) as ONE library call: per gap
+// step the child weights of every item (TreeLearning.aggregateWeights, jtm/.../optim/TreeLearning.scala:152-174) and the exact greedy
+// re-balance of every parent node (:217-265) run on the device, projection and weights stay in HBM between the steps.
+// The reference's `numThreads` workers (JTM.scala:33-68: items of a node split while a level has fewer nodes than workers, contiguous
+// node ranges afterwards) are GPUs here: pass the engines of this JVM's GPUs as `workers` and the run is sharded over them inside the
+// library (RCCL all-gathers over xGMI), with the single-GPU projection bit for bit.
 package com.mass.hip
 
 class JTM(engine: HipEngine, itemIds: Array[Int], itemCodes: Array[Int], maxLevel: Int,
           rowOff: Array[Long], rowItemIds: Array[Int], gap: Int, seqLen: Int, hierarchical: Boolean, minLevel: Int,
-          useMask: Boolean) {
+          useMask: Boolean, workers: Array[HipEngine] = Array.empty) {
 
-  private def ancestorAtLevel(code: Int, level: Int): Int = {              // JTMTree.getAncestorAtLevel (JTMTree.scala:36-43)
-    var c = code
-    val depth = 31 - Integer.numberOfLeadingZeros(c + 1)
-    var d = depth
-    while (d > level) { c = (c - 1) >> 1; d -= 1 }
-    c
+  private val engines: Array[HipEngine] = if (workers.isEmpty) Array(engine) else workers
+  private val comms = new Array[Long](engines.length)
+  if (engines.length > 1) {
+    Native.commCreateAll(engines.length, engines.map(_.device), comms)                         // ncclCommInitAll: rank i on engines(i)
+    engines.zip(comms).foreach { case (e, c) => Native.commAttach(e.handle, c) }
   }
 
   def optimize(): Map[Int, Int] = {
     val n = itemIds.length
-    var node = new Array[Int](n)                                           // every item starts at the root
-    // itemSequenceMap goes to the device once; the loop over the gap steps is one call (scoring + greedy re-balance of every parent node
-    // on the device, projection and weights stay in HBM between the steps)
-    Native.jtmCacheRows(engine.handle, rowOff, rowItemIds, n.toLong, seqLen)
+    val node = new Array[Int](n)
+    // itemSequenceMap goes to every worker's device once; the loop over the gap steps is one call
+    engines.foreach(e => Native.jtmCacheRows(e.handle, rowOff, rowItemIds, n.toLong, seqLen))
     try {
-      Native.jtmOptimizeCached(engine.handle, itemCodes, n.toLong, maxLevel, gap, if (hierarchical) 1 else 0, minLevel,
+      Native.jtmOptimizeAll(engines.map(_.handle), engines.length, itemCodes, n.toLong, maxLevel, gap, if (hierarchical) 1 else 0, minLevel,
         if (useMask) 1 else 0, node, null)
-    } finally Native.jtmCacheRows(engine.handle, null, null, 0L, seqLen)
+    } finally engines.foreach(e => Native.jtmCacheRows(e.handle, null, null, 0L, seqLen))
     itemIds.zip(node).toMap
+  }
+
+  /** Release the communicators of a multi-GPU run (the engines stay the caller's). */
+  def close(): Unit = if (engines.length > 1) {
+    engines.foreach(e => Native.commAttach(e.handle, 0L))
+    comms.foreach(c => if (c != 0L) Native.commDestroy(c))
   }
 }

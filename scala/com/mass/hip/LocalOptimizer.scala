@@ -23,8 +23,8 @@ class LocalOptimizer(engines: Array[HipEngine], layerNegCounts: Array[Int], star
     for (i <- 0 until n) {
       val h = handles(i)
       val t = targets(i).length
-      Native.memcpyH2d(h, dSeq(i), intsToBytes(sequences(i)), 4L * t * seqLen)
-      Native.memcpyH2d(h, dTgt(i), intsToBytes(targets(i)), 4L * t)
+      Native.memcpyH2dI32(h, dSeq(i), sequences(i), 4L * t * seqLen)                             // int arrays go up as they are
+      Native.memcpyH2dI32(h, dTgt(i), targets(i), 4L * t)
       val rows = new Array[Long](1)
       Native.tdmSampleTrainBatchDev(h, dSeq(i), dTgt(i), t.toLong, seqLen, layerNegCounts, layerNegCounts.length, startSampleLevel,
         if (withProb) 1 else 0, tolerance, if (useMask) 1 else 0, seed + i, dCodes(i), dSeqs(i), dMask(i), dLabels(i), capRows, rows)
@@ -35,10 +35,5 @@ class LocalOptimizer(engines: Array[HipEngine], layerNegCounts: Array[Int], star
     if (n > 1) Native.allreduceGrads(handles, n)                                                 // syncGradients, :164-187
     handles.foreach(h => Native.adamStep(h, 1.0f / n))                                           // ... / realParallelism + Adam.optimize
     lossSum / n
-  }
-
-  private def intsToBytes(a: Array[Int]): Array[Byte] = {
-    val bb = java.nio.ByteBuffer.allocate(4 * a.length).order(java.nio.ByteOrder.LITTLE_ENDIAN)
-    bb.asIntBuffer().put(a); bb.array()
   }
 }

@@ -69,6 +69,17 @@ int main(int argc, char **argv) {
         itemRows[rowItems[k]].insert(itemRows[rowItems[k]].end(), rows.begin() + (ptrdiff_t)(k * (size_t)L), rows.begin() + (ptrdiff_t)((k + 1) * (size_t)L));
       dm::JTM jtm(eng, rd<int32_t>(d, "leaf_ids.i32"), rd<int32_t>(d, "leaf_codes.i32"), maxLevel, itemRows, 2, L);
       const auto proj = jtm.optimize();
+      {   // the multi-worker entry with a single worker (dm_jtm_optimize_all, n == 1) and a one-rank RCCL communicator attached
+        const auto again = jtm.optimizeAll({&eng});
+        dm_comm_t c1 = nullptr;
+        char id[DM_COMM_ID_BYTES];
+        if (dm_comm_unique_id(id) != DM_OK || dm_comm_create_rccl(1, 0, id, 0, &c1) != DM_OK) throw dm::Error(DM_ERR_HIP, "one-rank communicator");
+        eng.attachComm(c1);
+        const auto withComm = jtm.optimize();
+        eng.attachComm(nullptr);
+        dm_comm_destroy(c1);
+        std::printf("\"jtm_all_equal\": %s,\n", (again == proj && withComm == proj) ? "true" : "false");
+      }
       std::printf("\"jtm_projection\": [");
       bool first = true;
       for (auto &kv : proj) { std::printf("%s[%d, %d]", first ? "" : ", ", kv.first, kv.second); first = false; }

@@ -84,6 +84,7 @@ def test_cpp_facade_matches_python_mirror_and_oracle(tmp_path, fixture_tree, fix
     item_rows = {k: np.concatenate(v) for k, v in item_rows.items()}
     proj = JTM(eng, t["leaf_ids"], t["leaf_codes"], 12, item_rows, gap=2, seq_len=L).optimize()
     assert {a: b for a, b in out["jtm_projection"]} == proj
+    assert out["jtm_all_equal"] is True              # dm::JTM::optimizeAll({&eng}) and optimize() under a one-rank communicator
     codes = np.array([b for _, b in out["jtm_projection"]])
     assert len(codes) == 3706 and codes.min() >= 4095 and codes.max() <= 8190 and np.bincount(codes).max() == 1
     # ---- OTM

@@ -135,7 +135,19 @@ def test_din_forward_index_error(engine_fixture):
 
 
 # --------------------------------------------------------------------------- TDM beam search
-def test_tdm_canonical_query_matches_golden(engine_fixture):
+def _explained(engine, oracle_tree, oracle_din32, seqs_diff, beam, topk):
+    """Users whose device id list differs from the oracle's: the first prune whose ordered outcome differs must be a near-tie — every
+    pair of candidates the two sides order differently closer than 2 x (ATOL + RTOL |s|) on BOTH sides' scores (helpers.explain_users)."""
+    from helpers import explain_users, trace_levels
+    if len(seqs_diff) == 0:
+        return dict(differing_users=0, explained_by_near_tie=0, max_cut_gap=0.0, unexplained=[])
+    _, _, _, tc, ts, tn = engine.tdm_beam_search_trace(np.ascontiguousarray(seqs_diff), beam, topk)
+    ta = [trace_levels(tc, ts, tn, u) for u in range(len(seqs_diff))]
+    tb = [oracle_tree.recommend(oracle_din32, seqs_diff[u], topk, beam, trace=True)[2] for u in range(len(seqs_diff))]
+    return explain_users(oracle_tree, beam, topk, ta, tb, atol=ATOL, rtol=RTOL)
+
+
+def test_tdm_canonical_query_matches_golden(engine_fixture, oracle_tree, oracle_din32):
     from dismember_amd import TDM
     g = json.load(open(os.path.join(GOLDEN, "oracle_outputs.json")))
     tdm = TDM(engine_fixture, "din")
@@ -145,9 +157,10 @@ def test_tdm_canonical_query_matches_golden(engine_fixture):
         probs = np.array([r[1] for r in recs])
         ref_p = 1.0 / (1.0 + np.exp(-np.array(rec["logits"], np.float64)))
         assert len(ids) == len(rec["ids"])
-        # a near-tie may legitimately swap neighbours; everything else must be identical
         if ids != rec["ids"]:
-            assert sorted(ids) == sorted(rec["ids"]) or len(set(ids) ^ set(rec["ids"])) <= 2
+            # only a measured near-tie at a cut may change the list: locate the cut and check the gap on both sides' scores
+            r = _explained(engine_fixture, oracle_tree, oracle_din32, np.array([rec["query"]], np.int32), rec["beam"], rec["topk"])
+            assert r["differing_users"] == 1 and r["explained_by_near_tie"] == 1, r
         assert np.abs(np.sort(probs) - np.sort(ref_p)).max() < 5e-5
 
 
@@ -163,21 +176,28 @@ def test_tdm_trace_replay_fixture(engine_fixture, oracle_tree, oracle_din32, fix
 
 
 def test_tdm_end_to_end_ids_vs_oracle(engine_fixture, oracle_tree, oracle_din32, fixture_tree):
+    """End to end, each side with its own scores: id lists are bit-identical unless a prune sits on a near-tie.  Every differing user
+    is located (first prune whose ordered outcome differs) and the score gap at that cut is bounded on both sides — an unexplained
+    user is a bug (Recommender.scala:74-87 sorts by pred; rounding may only swap candidates closer than the rounding allowance)."""
     rng = np.random.default_rng(5)
-    U = 200
+    U = 600
     seqs = random_histories(rng, fixture_tree["leaf_ids"], U, 10)
-    ids, sc, cnt = engine_fixture.tdm_beam_search(seqs, 20, 10)
-    same = 0
-    for u in range(U):
-        oi, osc = oracle_tree.recommend(oracle_din32, seqs[u], 10, 20)
-        assert cnt[u] == oi.size
-        same += int(np.array_equal(ids[u, :cnt[u]], oi))
-        # scores of the common ids agree within tolerance
-        common = {int(i): float(s) for i, s in zip(oi, osc)}
-        for i, s in zip(ids[u, :cnt[u]], sc[u, :cnt[u]]):
-            if int(i) in common:
-                assert close(s, common[int(i)]).all()
-    assert same >= int(0.97 * U), same
+    for beam, topk in ((20, 10), (200, 50)):
+        ids, sc, cnt = engine_fixture.tdm_beam_search(seqs, beam, topk)
+        differ = []
+        for u in range(U):
+            oi, osc = oracle_tree.recommend(oracle_din32, seqs[u], topk, beam)
+            assert cnt[u] == oi.size
+            if not np.array_equal(ids[u, :cnt[u]], oi):
+                differ.append(u)
+            # scores of the common ids agree within tolerance
+            common = {int(i): float(s) for i, s in zip(oi, osc)}
+            for i, s in zip(ids[u, :cnt[u]], sc[u, :cnt[u]]):
+                if int(i) in common:
+                    assert close(s, common[int(i)]).all()
+        r = _explained(engine_fixture, oracle_tree, oracle_din32, seqs[differ], beam, topk)
+        assert r["differing_users"] == len(differ) and r["explained_by_near_tie"] == len(differ), (beam, r["unexplained"][:3])
+        assert len(differ) <= int(0.03 * U), len(differ)
 
 
 def test_tdm_consumed_and_widened_beam(engine_fixture, oracle_tree, oracle_din32, fixture_tree):

@@ -47,8 +47,9 @@ VOID_HOST = {
     "dm_comm_unique_id": {"id128": [("", "uint8_t")]},
     "dm_comm_create_rccl": {"id128": [("", "uint8_t")]},
     "dm_comm_all_gather_v": {"send": [("", "uint8_t")], "recv": [("", "uint8_t")]},
-    "dm_memcpy_h2d": {"src": [("", "uint8_t")]},
-    "dm_memcpy_d2h": {"dst": [("", "uint8_t")]},
+    # typed variants: a Scala Array[Int] / Array[Float] goes up (comes down) as it is — no ByteBuffer copy on the caller's side
+    "dm_memcpy_h2d": {"src": [("", "uint8_t"), ("I32", "int32_t"), ("F32", "float"), ("F64", "double")]},
+    "dm_memcpy_d2h": {"dst": [("", "uint8_t"), ("I32", "int32_t"), ("F32", "float"), ("F64", "double")]},
 }
 FIXED = {("dm_load_weights_din", "F32"): {"dtype": "DM_F32"}, ("dm_load_weights_din", "F64"): {"dtype": "DM_F64"}}   # args the variant pins
 HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: written out below
