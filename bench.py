@@ -855,6 +855,28 @@ def main():
                 "seconds": dtt6, "levels": len(losses6), "loss_first_level": float(losses6[0]), "loss_last_level": float(losses6[-1]),
                 "adam_rows_visited_last_step": eng.adam_last_step_rows()[0], "adam_active_rows_path": eng.adam_last_step_rows()[1],
                 "adam_dense_stream_bytes_per_level": 8 * 8 * npar6, "train_init_s": t_init6, "workers": world,
+                "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker",
+                "phases": tr6.last_stats()}
+            # the same iteration at the conf's own batch (configs/c3_otm_10m.conf: model.train_batch_size 8192 USERS per worker, label_num
+            # targets each: 3.3 M candidate rows per level), through the same library entry point (dm_otm_train_batch)
+            Ub6 = min(8192, Uo6)
+            label_num = 5
+            bseq6 = oc6[:Ub6]
+            btg6 = (first6 + orng.integers(0, 1 << depth6, size=(Ub6, label_num))).tolist()
+            tr6.train_batch(bseq6, btg6)
+            sync(); barrier()
+            t0 = time.perf_counter()
+            lossesb = tr6.train_batch(bseq6, btg6)
+            sync(); barrier()
+            dtb6 = max_over_ranks(time.perf_counter() - t0)
+            ph = tr6.last_stats()
+            otm64["train_iteration_batch_8192"] = {
+                "workload": "the same iteration at model.train_batch_size = %d users per worker x %d targets: %d levels x %d candidate rows"
+                            % (Ub6, label_num, len(lossesb), Ub6 * 2 * a.beam),
+                "seconds": dtb6, "users_per_s": world * Ub6 / dtb6, "rows_per_s": world * ph["rows_trained"] / dtb6, "levels": len(lossesb),
+                "loss_first_level": float(lossesb[0]), "loss_last_level": float(lossesb[-1]),
+                "phases": ph, "host_side_s": max(0.0, dtb6 - sum(ph[k] for k in ("pseudo_targets_s", "beam_search_s", "forward_backward_s", "exchange_s", "adam_s"))),
+                "adam_rows_visited_last_step": eng.adam_last_step_rows()[0],
                 "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker"}
         except Exception as ex:
             otm64 = dict(otm64 or {}, error=repr(ex))

@@ -36,6 +36,10 @@ class SampleOpts(C.Structure):
     _fields_ = [("start_level", C.c_int), ("with_prob", C.c_int), ("tolerance", C.c_int), ("use_mask", C.c_int), ("seed", C.c_uint64)]
 
 
+class OtmTrainOpts(C.Structure):
+    _fields_ = [("beam", C.c_int), ("leaf_level", C.c_int), ("use_mask", C.c_int), ("target_mode", C.c_int)]
+
+
 class SearchOpts(C.Structure):
     _fields_ = [("beam", C.c_int), ("topk", C.c_int), ("use_mask", C.c_int), ("widen_consumed", C.c_int)]
 
@@ -77,6 +81,9 @@ SIGNATURES = {
     "dm_otm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_double)]),
     "dm_otm_rebalance": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), i32p, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, i32p]),
+    "dm_otm_train_batch": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, i64p, i32p, C.POINTER(OtmTrainOpts), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "dm_otm_pseudo_targets": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, i64p, i32p, C.POINTER(OtmTrainOpts), i32p, C.POINTER(C.c_double), i32p]),
+    "dm_otm_train_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "dm_train_init": (C.c_int, [C.c_void_p, C.POINTER(AdamOpts)]),
     "dm_train_forward_backward": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int64, f32p, C.c_int64, C.c_int, f32p]),
     "dm_adam_step": (C.c_int, [C.c_void_p, C.c_float]),

@@ -44,6 +44,13 @@ struct dm_jtm_stats {
   double scoring_s = 0, rebalance_s = 0, exchange_s = 0;
 };
 
+// what the last dm_otm_train_batch on a handle did (otm_train.hip.inc; dm_otm_train_stats)
+struct dm_otm_stats {
+  uint64_t users = 0, target_rows = 0, train_rows = 0;
+  int levels = 0;
+  double targets_s = 0, beam_s = 0, fwdbwd_s = 0, exchange_s = 0, adam_s = 0;
+};
+
 struct dm_ctx {
   int device = 0;
   int n_cu = 0;
@@ -156,6 +163,7 @@ struct dm_ctx {
   struct dm_comm *comm = nullptr;
   dm_sync_stats sync_stats{};
   dm_jtm_stats jtm_stats{};
+  dm_otm_stats otm_stats{};
   void *d_sync = nullptr;
   size_t sync_bytes = 0;
 };
@@ -1759,6 +1767,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "otm64.hip.inc"
 #include "comm.hip.inc"
 #include "jtm_sharded.hip.inc"
+#include "otm_train.hip.inc"
 #include "checkpoint.hip.inc"
 
 // ---- device memory helpers

@@ -1,13 +1,12 @@
-"""OTM training on the GPU: pseudo targets, fixed-weights beam nodes and one optimizer step per level.
+"""OTM training on the GPU: one LocalOptimizer iteration as ONE library call (dm_otm_train_batch).
 
 Mirror of otm/src/main/scala/com/mass/otm/optim/LocalOptimizer.scala:55-140 with
 OTMTree.optimalPseudoTargets / beamSearchNodes (otm/.../tree/OTMTree.scala:27-91,104-212) and
-MiniBatch.batchTransform (otm/.../dataset/MiniBatch.scala:17-40).  Every model evaluation runs on the device
-(general-rows forward, beam kernel in OTM mode with its per-level trace, training kernels); the label bookkeeping
-is small host code.  The arithmetic follows the loaded model: an f64 model (the reference's DIN[Double]) is searched by
-the fp64 beam kernel and trained by the fp64 kernels with fp64 Adam state; an f32 model runs the throughput kernels.
-
-computeTargets' mirrored prediction offsets (a reference quirk, OTMTree.scala:115-128) are reproduced.
+MiniBatch.batchTransform (otm/.../dataset/MiniBatch.scala:17-40).  Pseudo targets (sibling pairs, the mirrored prediction
+offsets of computeTargets — a reference quirk, OTMTree.scala:115-128 — and clip(sum of children)), the beam nodes and the
+per-level label join all run on the device inside the library (csrc/otm_train.hip.inc); this class only flattens the batch.
+The arithmetic follows the loaded model: an f64 model (the reference's DIN[Double]) is searched by the fp64 beam kernel and
+trained by the fp64 kernels with fp64 Adam state; an f32 model runs the throughput kernels.
 """
 import ctypes as C
 
@@ -55,62 +54,53 @@ class OTMTrainer:
         return [[list(zip(tc[u, lv, :tn[u, lv]].tolist(), ts[u, lv, :tn[u, lv]].tolist())) for u in range(U)]
                 for lv in range(levels)]
 
-    def compute_targets(self, children, seqs):
-        pos, neg, neg_labels, rows = [], [], [], []
-        for u, nodes in enumerate(children):
-            ids = [n for n, _ in nodes]
-            sib = [n - 1 if n % 2 == 0 else n + 1 for n in ids]
-            lut = dict(nodes)
-            pos += ids; neg += sib
-            neg_labels += [lut.get(s, 0.0) for s in sib]
-            rows += [seqs[u]] * len(ids)
-        if pos:
-            preds = self._forward(pos + neg, rows + rows)          # one launch for both children (OTMTree.scala:159-164)
-            pos_preds, neg_preds = preds[:len(pos)], preds[len(pos):]
-        else:
-            pos_preds = neg_preds = np.zeros(0, np.float32)
-        out = [None] * len(children)
-        offset = 0
-        for u in range(len(children) - 1, -1, -1):                 # foldRight with offset from 0 (reference quirk)
-            acc = {}
-            for i, (n, score) in enumerate(children[u]):
-                idx = offset + i
-                label = score if pos_preds[idx] >= neg_preds[idx] else neg_labels[idx]
-                par = (n - 1) >> 1
-                acc[par] = acc.get(par, 0.0) + label
-            out[u] = {k: min(1.0, max(0.0, v)) for k, v in acc.items()}
-            offset += len(children[u])
+    def _flatten(self, seqs, target_nodes):
+        seqs = _i32(seqs).reshape(-1, self.L)
+        off = np.zeros(seqs.shape[0] + 1, np.int64)
+        off[1:] = np.cumsum([len(t) for t in target_nodes])
+        flat = _i32(np.concatenate([np.asarray(t, np.int32).ravel() for t in target_nodes])) if off[-1] > 0 else np.zeros(1, np.int32)
+        return seqs, off, flat
+
+    def _opts(self, target_mode):
+        return N.OtmTrainOpts(self.beam, self.leaf_level, 1, {"pseudo": 0, "normal": 1}[target_mode])
+
+    def optimal_pseudo_targets(self, target_nodes, seqs, target_mode="pseudo"):
+        """OTMTree.optimalPseudoTargets (or normalTargets) on the device (dm_otm_pseudo_targets): list over the levels
+        start+1 .. leaf of per-user {node: label} in the reference's list order (first appearance)."""
+        seqs, off, flat = self._flatten(seqs, target_nodes)
+        U, levels, NT = seqs.shape[0], self.leaf_level - self.start_level, max(int(off[-1]), 1)
+        nodes = np.empty((levels, NT), np.int32); labels = np.empty((levels, NT), np.float64); counts = np.empty((levels, U), np.int32)
+        opts = self._opts(target_mode)
+        self.e._chk(N.lib().dm_otm_pseudo_targets(self.e._h, _p(seqs, N.i32p), U, self.L, _p(off, N.i64p), _p(flat, N.i32p), C.byref(opts),
+                                                  _p(nodes, N.i32p), labels.ctypes.data_as(C.POINTER(C.c_double)), _p(counts, N.i32p)))
+        out = []
+        for lv in range(levels):
+            per = []
+            for u in range(U):
+                b, n = int(off[u]), int(counts[lv, u])
+                d = {}
+                for k, v in zip(nodes[lv, b:b + n].tolist(), labels[lv, b:b + n].tolist()):
+                    d.setdefault(k, v)              # normal mode may repeat an ancestor: List.find sees the first
+                per.append(d)
+            out.append(per)
         return out
 
-    def optimal_pseudo_targets(self, target_nodes, seqs):
-        cur = [[(int(t), 1.0) for t in tl] for tl in target_nodes]
-        levels = [[dict(c) for c in cur]]
-        for _ in range(self.leaf_level - 1, self.start_level, -1):
-            nxt = self.compute_targets(cur, seqs)
-            levels.insert(0, nxt)
-            cur = [list(d.items()) for d in nxt]
-        return levels
-
-    def train_batch(self, seqs, target_nodes):
+    def train_batch(self, seqs, target_nodes, target_mode="pseudo"):
         """One LocalOptimizer iteration for a batch of users (seqs: node ids, -1 pad; target_nodes: leaf node ids per
-        user).  Returns the per-level losses (one Adam step per level, LocalOptimizer.scala:73-80)."""
-        seqs = _i32(seqs)
-        targets = self.optimal_pseudo_targets(target_nodes, seqs)
-        beams = self.beam_search_nodes(seqs)
-        losses = []
-        for lv, (tl, bl) in enumerate(zip(targets, beams)):
-            codes, rows, labels = [], [], []
-            for u, cand in enumerate(bl):
-                for n, _ in cand:
-                    codes.append(n); rows.append(seqs[u]); labels.append(tl[u].get(n, 0.0))
-            rows = _i32(rows).reshape(-1, self.L)
-            pad = np.flatnonzero(rows.reshape(-1) == -1).astype(np.int32)
-            loss = self.e.train_forward_backward(_i32(codes), rows, pad, np.asarray(labels, np.float32))
-            world = 1
-            if self.comm is not None:
-                world = self.comm.world
-                self.e.train_sync_gradients()
-                loss = self.comm.allreduce(float(loss)) / world
-            losses.append(loss)
-            self.e.adam_step(1.0 / world)
-        return losses
+        user) in one library call.  Returns the per-level losses, averaged over the workers when a communicator is attached
+        (one gradient exchange and one Adam step per level, LocalOptimizer.scala:73-80)."""
+        seqs, off, flat = self._flatten(seqs, target_nodes)
+        levels = self.leaf_level - self.start_level
+        losses = (C.c_double * levels)()
+        nl = C.c_int(0)
+        opts = self._opts(target_mode)
+        self.e._chk(N.lib().dm_otm_train_batch(self.e._h, _p(seqs, N.i32p), seqs.shape[0], self.L, _p(off, N.i64p), _p(flat, N.i32p),
+                                               C.byref(opts), losses, C.byref(nl)))
+        return [float(losses[i]) for i in range(nl.value)]
+
+    def last_stats(self):
+        """dm_otm_train_stats: users, levels, rows of the pseudo-target forwards, rows trained; seconds per phase."""
+        o = (C.c_uint64 * 6)(); t = (C.c_double * 5)()
+        self.e._chk(N.lib().dm_otm_train_stats(self.e._h, o, t))
+        return {"users": int(o[0]), "levels": int(o[1]), "pseudo_target_forward_rows": int(o[2]), "rows_trained": int(o[3]),
+                "pseudo_targets_s": t[0], "beam_search_s": t[1], "forward_backward_s": t[2], "exchange_s": t[3], "adam_s": t[4]}

@@ -212,6 +212,39 @@ class OTM {
   int leafLevel_ = 0;
 };
 
+// OTM training: LocalOptimizer's iteration (otm/src/main/scala/com/mass/otm/optim/LocalOptimizer.scala:55-109) for one worker's batch
+// as one library call (dm_otm_train_batch): pseudo targets, beam nodes and the per-level label join on the device, one forward /
+// backward + gradient exchange (when the engine carries a communicator with > 1 rank: every rank calls trainBatch) + Adam per level.
+class OTMLocalOptimizer {
+ public:
+  OTMLocalOptimizer(Engine &engine, int leafLevel, int beamSize, int seqLen, double learningRate, bool useMask = true,
+                    const std::string &targetMode = "pseudo")
+      : e_(engine), L_(seqLen) {
+    opts_.beam = beamSize; opts_.leaf_level = leafLevel; opts_.use_mask = useMask ? 1 : 0; opts_.target_mode = targetMode == "normal" ? 1 : 0;
+    dm_adam_opts a{learningRate, 0.0, 0.9, 0.999, 1e-8};                 // Adam defaults, scalann/.../optim/Adam.scala:10-16
+    e_.check(dm_train_init(e_.handle(), &a));
+  }
+  // sequences [U x seqLen] node ids (-1 = padding), targetNodes[u] = the user's target leaf nodes; -> the per-level losses
+  std::vector<double> trainBatch(const std::vector<int32_t> &sequences, const std::vector<std::vector<int32_t>> &targetNodes) {
+    const int64_t U = (int64_t)targetNodes.size();
+    if ((int64_t)sequences.size() != U * L_) throw Error(DM_ERR_INVALID, "OTMLocalOptimizer: sequences must hold U x seqLen ids");
+    std::vector<int64_t> off((size_t)U + 1, 0);
+    std::vector<int32_t> flat;
+    for (int64_t u = 0; u < U; u++) { flat.insert(flat.end(), targetNodes[(size_t)u].begin(), targetNodes[(size_t)u].end()); off[(size_t)u + 1] = (int64_t)flat.size(); }
+    if (flat.empty()) flat.push_back(0);
+    std::vector<double> losses(64, 0.0);
+    int n = 0;
+    e_.check(dm_otm_train_batch(e_.handle(), sequences.data(), U, L_, off.data(), flat.data(), &opts_, losses.data(), &n));
+    losses.resize((size_t)n);
+    return losses;
+  }
+
+ private:
+  Engine &e_;
+  int L_;
+  dm_otm_train_opts opts_{};
+};
+
 class DeepRetrieval {
  public:
   // itemIdMapping: item -> internal id (MappingOp.itemIdMapping); model and path table are loaded into the engine with

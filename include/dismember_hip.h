@@ -322,6 +322,35 @@ int dm_train_sync_stats(dm_handle_t h, uint64_t *out8);
  * thread (hs[i] must carry rank i); n == 1 is dm_train_sync_gradients. */
 int dm_allreduce_grads(dm_handle_t *hs, int n);
 
+/* ---- OTM training iteration (otm/src/main/scala/com/mass/otm/optim/LocalOptimizer.scala:55-109) ---------------------------
+ * One LocalOptimizer iteration for this worker's batch of U users, every list on the device:
+ *   targets   OTMTree.optimalPseudoTargets (O/tree/OTMTree.scala:27-46; computeTargets :104-129 with its mirrored prediction offsets,
+ *             computeChildrenScores :131-165) — target_mode 0 — or OTMTree.normalTargets (:50-63) — target_mode 1;
+ *   beams     OTMTree.beamSearchNodes (:67-91), weights fixed (the per-level trace of the OTM beam search);
+ *   per level MiniBatch.batchTransform (O/dataset/MiniBatch.scala:17-40) -> trainBatch (LocalOptimizer.scala:111-131) ->
+ *             syncGradients (:133-141: dm_train_sync_gradients when a communicator with > 1 rank is attached — the call is then
+ *             COLLECTIVE) -> Adam.optimize with 1 / ranks.
+ * seq_codes [U*L] node ids (-1 = padding); target_off [U+1] / target_nodes: CSR of every user's target LEAF nodes (OTMSample.targetItems
+ * after the item -> node mapping); level_losses [leaf_level - floor(log2 beam)] receives the per-level losses averaged over the ranks
+ * (levelLoss of :73-80, first level first), *n_levels their number.  Needs dm_train_init; runs in the loaded dtype (the reference's
+ * OTM is DIN[Double]: fp64 search, fp64 training); the Adam step of every level moves the weights, like the reference. */
+typedef struct {
+  int beam;          /* beamSize */
+  int leaf_level;    /* leaf level of the complete tree; the start level is floor(log2 beam) */
+  int use_mask;      /* 1 for DIN */
+  int target_mode;   /* 0 "pseudo" (optimalPseudoTargets), 1 "normal" (normalTargets) */
+} dm_otm_train_opts;
+int dm_otm_train_batch(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, const int64_t *target_off, const int32_t *target_nodes,
+                       const dm_otm_train_opts *opts, double *level_losses, int *n_levels);
+/* the target lists alone (parity instrumentation; no training state needed): out_nodes / out_labels [levels x target_off[U]] in the CSR of
+ * target_off (a user's list at a level occupies the first out_counts[level][u] of its slots; unused slots hold -1 / 0), out_counts
+ * [levels x U]; level index li <-> tree level floor(log2 beam) + 1 + li. */
+int dm_otm_pseudo_targets(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, const int64_t *target_off, const int32_t *target_nodes,
+                          const dm_otm_train_opts *opts, int32_t *out_nodes, double *out_labels, int32_t *out_counts);
+/* measurement — the last dm_otm_train_batch on this handle: out6 = users, levels, rows of the pseudo-target forwards, rows trained, 0, 0;
+ * secs5 = pseudo targets, beam search, forward / backward, gradient exchange, Adam (seconds) */
+int dm_otm_train_stats(dm_handle_t h, uint64_t *out6, double *secs5);
+
 /* Level-wise negative sampling + batch expansion, ON THE DEVICE: NegativeSampler.sample
  * (tdm/.../utils/NegativeSampler.scala:76-158: uniform and sample_with_probability modes) + MiniBatch.convert
  * (tdm/.../dataset/MiniBatch.scala:49-88).  One wave per (target, level); counter-based stream splitmix64(seed, target,

@@ -2,6 +2,7 @@
 program (tests/cpp/facade_test.cpp, built here with g++) against the Python mirror and the CPU oracle on the reference's
 bundled tree + trained models."""
 import json
+import re
 import os
 import subprocess
 import sys
@@ -57,7 +58,9 @@ def test_cpp_facade_matches_python_mirror_and_oracle(tmp_path, fixture_tree, fix
     dpi[2].astype(np.int32).tofile(d / "dr_items.i32")
     dr_query_ids = drng.integers(0, dn, dL)
     (1000 + 3 * dr_query_ids).astype(np.int32).tofile(d / "dr_query.i32")
-    out = json.loads(subprocess.check_output([exe, str(d)], env=dict(os.environ), timeout=300))
+    raw = subprocess.check_output([exe, str(d)], env=dict(os.environ), timeout=300).decode()
+    # RCCL prints its version banner on stdout when the program creates its one-rank communicator: keep the program's own lines
+    out = json.loads("\n".join(ln for ln in raw.splitlines() if not re.match(r"^(RCCL version|HIP version|ROCm version|Hostname|Librccl path)\s*:", ln)))
 
     # ---- the Python mirror over the same library
     eng = Engine(0)

@@ -652,6 +652,45 @@ def test_otm_pseudo_targets_and_beam_nodes(fixture_w64, fixture_otm_mapping, ora
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_otm_targets_on_device_ragged_batch(fixture_w64, fixture_otm_mapping, oracle_din64, dtype):
+    """dm_otm_pseudo_targets over a ragged batch (users with no target, one target, sibling targets, repeated targets; 70 users so
+    that the mirrored prediction offsets of computeTargets — OTMTree.scala:115-128 — cross users with different list lengths): node
+    lists, their order (first appearance) and labels equal the oracle's restatement fed with the SAME predictions; "normal" targets
+    (OTMTree.normalTargets, :50-63) are the targets' ancestors with label 1."""
+    from dismember_amd import Engine
+    from dismember_amd.otm_train import OTMTrainer
+    from oracle import otm_oracle as oo
+    rng = np.random.default_rng(79)
+    eng = Engine(0)
+    eng.load_weights_din(fixture_w64.astype(dtype), 16, 8191)
+    tr = OTMTrainer(eng, leaf_level=12, beam=20)
+    U = 70
+    codes, targets = _otm_problem(rng, fixture_otm_mapping, U)
+    targets[3] = []                                                    # a user without targets
+    targets[5] = [targets[5][0], targets[5][0] ^ 1 if targets[5][0] % 2 else targets[5][0] - 1]     # will be replaced below
+    t0 = 4095 + 2 * 117                                                # an even leaf node id ...
+    targets[5] = [t0 - 1, t0]                                          # ... and its sibling (both present: negLabels reads the list)
+    targets[9] = [t0, t0, t0 + 40]                                     # a repeated target (targetItems may repeat)
+    targets[U - 1] = [4095 + k for k in range(0, 14, 2)]               # a long list at the right end (offset 0 of the fold)
+    tg = tr.optimal_pseudo_targets(targets, codes)
+    tref = oo.optimal_pseudo_targets(oracle_din64, targets, codes, 10, tr.start_level, 12, pred_fn=lambda n, s: tr._forward(n, s))
+    assert len(tg) == len(tref) == 12 - tr.start_level
+    for lv in range(len(tref)):
+        for u in range(U):
+            assert list(tg[lv][u].keys()) == list(tref[lv][u].keys()), (lv, u)          # same nodes in the same (first-appearance) order
+            assert all(tg[lv][u][k] == tref[lv][u][k] for k in tg[lv][u]), (lv, u)
+            assert all(v in (0.0, 1.0) for v in tg[lv][u].values())
+    assert tg[-1][3] == {} and all(tg[lv][3] == {} for lv in range(len(tg)))
+    nt = tr.optimal_pseudo_targets(targets, codes, target_mode="normal")
+    for u in range(U):
+        anc = list(dict.fromkeys(targets[u]))
+        for lv in range(len(nt) - 1, -1, -1):
+            assert list(nt[lv][u].keys()) == anc and all(v == 1.0 for v in nt[lv][u].values())
+            anc = list(dict.fromkeys((a - 1) >> 1 for a in anc))
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_otm_train_batch_vs_oracle(fixture_w64, fixture_otm_mapping, oracle, dtype):
     """One LocalOptimizer iteration (O/optim/LocalOptimizer.scala:55-109): per-level losses against the f64 oracle that
     trains on the same rows (rows and labels taken from the product, so only the numerics are compared).  float64 (the
@@ -668,8 +707,10 @@ def test_otm_train_batch_vs_oracle(fixture_w64, fixture_otm_mapping, oracle, dty
     codes, targets = _otm_problem(rng, fixture_otm_mapping, 8)
     tg = tr.optimal_pseudo_targets(targets, codes)
     bm = tr.beam_search_nodes(codes)
-    losses = tr.train_batch(codes, targets)
+    losses = tr.train_batch(codes, targets)                 # ONE library call: dm_otm_train_batch
     assert len(losses) == 12 - tr.start_level and all(np.isfinite(losses))
+    st = tr.last_stats()
+    assert st["users"] == 8 and st["levels"] == len(losses) and st["rows_trained"] == sum(len(bm[lv][u]) for lv in range(len(bm)) for u in range(8))
     opt = oracle.Adam(w.size, np.float64, lr=1e-3)
     ref_losses = []
     for lv in range(len(tg)):

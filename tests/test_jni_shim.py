@@ -75,7 +75,7 @@ def test_scala_facades_call_existing_natives():
     methods = _native_methods()
     d = os.path.join(ROOT, "scala", "com", "mass", "hip")
     facades = [f for f in os.listdir(d) if f.endswith(".scala") and f != "Native.scala"]
-    assert sorted(facades) == ["DeepRetrieval.scala", "HipEngine.scala", "JTM.scala", "LocalOptimizer.scala", "OTM.scala", "TDM.scala"]
+    assert sorted(facades) == ["DeepRetrieval.scala", "HipEngine.scala", "JTM.scala", "LocalOptimizer.scala", "OTM.scala", "OTMLocalOptimizer.scala", "TDM.scala"]
     calls = 0
     for f in facades:
         text = open(os.path.join(d, f)).read()

@@ -31,6 +31,7 @@ OUT_SCALA = os.path.join(ROOT, "scala", "com", "mass", "hip", "Native.scala")
 STRUCTS = {      # option structs flattened into scalars: (field, C type) in declaration order
     "dm_tdm_search_opts": [("beam", "int"), ("topk", "int"), ("use_mask", "int"), ("widen_consumed", "int")],
     "dm_adam_opts": [("lr", "double"), ("lr_decay", "double"), ("beta1", "double"), ("beta2", "double"), ("eps", "double")],
+    "dm_otm_train_opts": [("beam", "int"), ("leaf_level", "int"), ("use_mask", "int"), ("target_mode", "int")],
     "dm_sample_opts": [("start_level", "int"), ("with_prob", "int"), ("tolerance", "int"), ("use_mask", "int"), ("seed", "uint64_t")],
 }
 SCALAR = {"int": ("jint", "Int"), "int32_t": ("jint", "Int"), "int64_t": ("jlong", "Long"), "uint64_t": ("jlong", "Long"),
