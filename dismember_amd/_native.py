@@ -53,6 +53,7 @@ SIGNATURES = {
     "dm_last_error": (C.c_char_p, [C.c_void_p]),
     "dm_synchronize": (C.c_int, [C.c_void_p]),
     "dm_load_tree_tdm": (C.c_int, [C.c_void_p, i32p, i32p, u8p, C.c_int64, C.c_int]),
+    "dm_load_tree_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "dm_load_id_maps": (C.c_int, [C.c_void_p, i32p, i32p, C.c_int64]),
     "dm_tdm_id_to_code": (C.c_int, [C.c_void_p, i32p, C.c_int, i32p, i32p, C.POINTER(C.c_int)]),
     "dm_level_start": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1769,6 +1769,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "jtm_sharded.hip.inc"
 #include "otm_train.hip.inc"
 #include "checkpoint.hip.inc"
+#include "tree_file.hip.inc"
 
 // ---- device memory helpers
 int dm_dev_alloc(dm_handle_t h, size_t bytes, void **dptr) {

@@ -54,12 +54,13 @@ class Engine:
                                            codes.size, int(max_level)))
 
     def load_tree_file(self, path):
-        """DistTree.loadData (tdm/.../tree/DistTree.scala:40-87): a reference tree file -> device index."""
+        """TDM.loadTree / TDMOp.initTree(treePbPath) (tdm/.../model/TDM.scala:50-52; DistTree.loadData, tdm/.../tree/DistTree.scala:40-87):
+        a reference tree file -> device index + id maps + node probabilities, parsed inside the library (dm_load_tree_file)."""
+        self._chk(N.lib().dm_load_tree_file(self._h, os.fsencode(path)))
+        with open(path, "rb") as f:                    # max_level for the Python-side bookkeeping: the tree_meta record closes the file
+            data = f.read()
         from . import tree_io
-        t = tree_io.read_tree_file(path)
-        self.load_tree(t["codes"], t["ids"], t["is_leaf"], t["max_level"])
-        self.load_id_maps(t["leaf_ids"], t["leaf_codes"])
-        return t
+        self.max_level = tree_io.read_max_level(data)
 
     def load_id_maps(self, leaf_item_ids, leaf_codes):
         a, b = _i32(leaf_item_ids), _i32(leaf_codes)
@@ -130,9 +131,11 @@ class Engine:
         import struct
         with open(path, "rb") as f:
             hd = f.read(8 + 8 * 4 + 4 * 8)
-        _, dtype, E, _, _, _, _, _ = struct.unpack("<8i", hd[8:40])
+        _, dtype, E, max_level, has_tree, _, _, _ = struct.unpack("<8i", hd[8:40])
         num_index, = struct.unpack("<q", hd[40:48])
         self.E, self.dtype, self.num_index = int(E), np.dtype(np.float64 if dtype == 1 else np.float32), int(num_index)
+        if has_tree:
+            self.max_level = int(max_level)
 
     def download_weights(self):
         """Host copy of the compact vector built by load_weights_din_synthetic (for the CPU oracle)."""

@@ -23,6 +23,21 @@ class TDM:
         self.engine = engine
         self.use_mask = model_name.lower() == "din"   # TDM.apply, TDM.scala:26-29
 
+    def predict(self, sequence, target):
+        """TDM.predict(sequence, target): Double (TDM.scala:10-15): the model's probability for ONE (history, target item) pair —
+        idToCode over sequence ++ target, one forward, sigmoid in double.  (The reference hands the model a single [1, L + 1] tensor,
+        which only its DeepFM graph accepts; for DIN the same row goes through Module.forward(Table(item, sequence, mask)).)"""
+        seq = np.asarray(sequence, dtype=np.int32).ravel()
+        codes, mask_pos = self.engine.id_to_code(np.concatenate([seq, np.asarray([target], np.int32)]))
+        pad = mask_pos[mask_pos < seq.size].astype(np.int32) if self.use_mask else np.zeros(0, np.int32)
+        logit = self.engine.din_forward(codes[-1:], codes[None, :-1], pad)
+        return float(sigmoid(np.float32(logit[0])))
+
+    @staticmethod
+    def load_tree(engine, tree_pb_path):
+        """TDM.loadTree(treePbPath) (TDM.scala:50-52 -> TDMOp.initTree): the reference's tree file into the engine."""
+        engine.load_tree_file(tree_pb_path)
+
     def recommend(self, sequence, topk, candidate_num):
         """TDM.recommend(sequence, topk, candidateNum): Array[(Int, Double)] (TDM.scala:17-22)."""
         seq = np.asarray(sequence, dtype=np.int32)

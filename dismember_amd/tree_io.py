@@ -130,6 +130,21 @@ def read_tree_bytes(data):
                 leaf_ids=pairs[:, 0].copy(), leaf_codes=pairs[:, 1].copy(), max_level=int(max_level))
 
 
+def read_max_level(data):
+    """TreeMeta.max_level of a tree file's bytes (the tree_meta record), without materialising the nodes."""
+    i = 0
+    while i < len(data):
+        (n,) = struct.unpack(">i", data[i:i + 4])
+        i += 4
+        if b"tree_meta" in data[i:i + min(n, 24)]:
+            kv = dict(_fields(data[i:i + n]))
+            for f, v in _fields(kv.get(2, b"")):
+                if f == 1:
+                    return int(v)
+        i += n
+    raise ValueError("tree file has no tree_meta record")
+
+
 def read_tree_file(path):
     with open(path, "rb") as f:
         return read_tree_bytes(f.read())

@@ -139,6 +139,27 @@ class TDM {
     std::transform(m.begin(), m.end(), m.begin(), ::tolower);
     useMask_ = (m == "din");                         // TDM.apply, TDM.scala:26-29
   }
+  // TDM.predict(sequence, target): Double (TDM.scala:10-15): idToCode over sequence ++ target, one forward, sigmoid in double
+  double predict(const std::vector<int32_t> &sequence, int32_t target) const {
+    std::vector<int32_t> all(sequence);
+    all.push_back(target);
+    std::vector<int32_t> codes(all.size()), maskPos(all.size());
+    int nMask = 0;
+    e_.check(dm_tdm_id_to_code(e_.handle(), all.data(), (int)all.size(), codes.data(), maskPos.data(), &nMask));
+    std::vector<int32_t> pad;
+    if (useMask_) for (int i = 0; i < nMask; i++) if (maskPos[(size_t)i] < (int32_t)sequence.size()) pad.push_back(maskPos[(size_t)i]);
+    float logit = 0.f;
+    const int32_t dummy = 0;
+    e_.check(dm_din_forward(e_.handle(), &codes.back(), codes.data(), pad.empty() ? &dummy : pad.data(), (int64_t)pad.size(), 1, (int)sequence.size(), &logit));
+    return sigmoid((double)logit);
+  }
+  // TDM.saveModel / loadModel / loadTree companions (TDM.scala:32-54): one flat checkpoint; the reference's own tree file
+  static void saveModel(const std::string &modelPath, const Engine &engine) { engine.saveModel(modelPath); }
+  static TDM loadModel(Engine &engine, const std::string &modelPath, const std::string &modelName = "din") {
+    engine.loadModel(modelPath);
+    return TDM(engine, modelName);
+  }
+  static void loadTree(Engine &engine, const std::string &treePbPath) { engine.check(dm_load_tree_file(engine.handle(), treePbPath.c_str())); }
   // TDM.recommend(sequence, topk, candidateNum): Array[(Int, Double)]
   Recs recommend(const std::vector<int32_t> &sequence, int topk, int candidateNum) const {
     return recommendBatch(sequence, 1, (int)sequence.size(), topk, candidateNum)[0];

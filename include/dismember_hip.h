@@ -64,6 +64,10 @@ int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_id
                      int64_t n_nodes, int max_level);
 /* idCodeMap + nonLeafOffset + maxCode (DistTree.loadItems, T/tree/DistTree.scala:26-38) */
 int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *leaf_codes, int64_t n);
+/* TDM.loadTree / TDMOp.initTree(treePbPath) (T/model/TDM.scala:50-52, T/operator/TDMOp.scala:61-82): the reference's own tree file —
+ * [int32 BE length][KVItem] records written by TreeBuilder.build (T/tree/TreeBuilder.scala:23-101) / JTMTree.writeTree, read by
+ * DistTree.loadData (T/tree/DistTree.scala:40-87) — parsed in the library: dm_load_tree_tdm + dm_load_id_maps + dm_tdm_set_node_probs. */
+int dm_load_tree_file(dm_handle_t h, const char *path);
 /* TDMTree.idToCode (T/tree/TDMTree.scala:35-56); host-side helper, same logic the kernels run on device */
 int dm_tdm_id_to_code(dm_handle_t h, const int32_t *item_ids, int n, int32_t *codes, int32_t *mask_pos,
                       int *n_mask);

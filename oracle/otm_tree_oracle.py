@@ -9,16 +9,21 @@ Parity status: unpinned at the JVM boundary (otm/src/test/scala/TreeConstruction
 only); this file is pinned on those invariants and on hand-checkable cases in tests/test_otm_tree.py.
 """
 import functools
+import struct
 
 import numpy as np
 
 
 def java_double_compare(x, y):
+    """java.lang.Double.compare (what Ordering[Double] resolves to): numeric order, then doubleToLongBits — -0.0 < 0.0, one
+    canonical NaN above everything."""
     if x < y:
         return -1
     if x > y:
         return 1
-    return 0          # NaN / signed zeros do not occur in the test inputs
+    a = struct.unpack("<q", struct.pack("<d", float("nan") if x != x else float(x)))[0] if x == x else 0x7ff8000000000000
+    b = struct.unpack("<q", struct.pack("<d", float("nan") if y != y else float(y)))[0] if y == y else 0x7ff8000000000000
+    return 0 if a == b else (-1 if a < b else 1)
 
 
 def get_ancestor_at_level(node, level):

@@ -4,6 +4,17 @@ package com.mass.hip
 
 class TDM(engine: HipEngine, useMask: Boolean) extends Serializable {
 
+  /** TDM.predict(sequence, target): Double (TDM.scala:10-15): idToCode over sequence ++ target, one forward, sigmoid in double. */
+  def predict(sequence: Array[Int], target: Int): Double = {
+    val all = sequence :+ target
+    val codes = new Array[Int](all.length); val maskPos = new Array[Int](all.length); val nMask = new Array[Int](1)
+    Native.tdmIdToCode(engine.handle, all, all.length, codes, maskPos, nMask)
+    val pad = if (useMask) maskPos.take(nMask(0)).filter(_ < sequence.length) else Array.emptyIntArray
+    val logit = new Array[Float](1)
+    Native.dinForwardF32(engine.handle, Array(codes.last), codes.init, pad, pad.length.toLong, 1L, sequence.length, logit)
+    TDM.sigmoid(logit(0))
+  }
+
   /** TDM.recommend(sequence, topk, candidateNum): Array[(Int, Double)] */
   def recommend(sequence: Array[Int], topk: Int, candidateNum: Int): Array[(Int, Double)] = {
     val ids = new Array[Int](topk); val sc = new Array[Float](topk); val n = new Array[Int](1)
@@ -34,5 +45,17 @@ class TDM(engine: HipEngine, useMask: Boolean) extends Serializable {
 
 object TDM {
   def apply(engine: HipEngine, modelName: String): TDM = new TDM(engine, modelName.toLowerCase == "din")
+
+  /** TDM.saveModel / loadModel (TDM.scala:32-48): one flat checkpoint (weights + index) instead of a Java-serialised module graph. */
+  def saveModel(modelPath: String, engine: HipEngine): Unit = Native.saveModel(engine.handle, modelPath)
+  def loadModel(engine: HipEngine, modelPath: String, modelName: String): TDM = {
+    val name = modelName.toLowerCase
+    require(name == "din", "the device scorer is DIN (DeepFM is outside the hot path)")
+    Native.loadModel(engine.handle, modelPath)
+    new TDM(engine, useMask = true)
+  }
+
+  /** TDM.loadTree(treePbPath) (TDM.scala:50-52 -> TDMOp.initTree): the reference's own tree file, parsed by the library. */
+  def loadTree(engine: HipEngine, treePbPath: String): Unit = Native.loadTreeFile(engine.handle, treePbPath)
   @inline def sigmoid(logit: Float): Double = 1.0 / (1 + java.lang.Math.exp(-logit))
 }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from dismember_amd import synth
-from helpers import random_din_weights, random_histories, synthetic_tree
+from helpers import CANONICAL_TDM_QUERY, random_din_weights, random_histories, synthetic_tree
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 1e-5
@@ -246,7 +246,8 @@ def test_jtm_rebalance_large_parent_equals_oracle(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("case", ["root", "four_parents", "many_parents", "gap3_tight", "gap1", "nan_zero"])
+@pytest.mark.parametrize("case", ["root", "four_parents", "many_parents", "gap3_tight", "gap1", "nan_zero", "gap6", "gap8_root",
+                                  "f64_root", "f64_parents", "f64_gap6", "f64_nan_zero"])
 def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
     """dm_jtm_rebalance_all runs every parent of a level on the device (jtm_rebalance_dev.hip.inc: rounds of stable compaction +
     one stable 64-bit radix sort on (parent | moved | descending weight key)); DM_JTM_REBALANCE=host keeps the per-parent host
@@ -256,16 +257,22 @@ def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
     from dismember_amd import Engine
     from dismember_amd import _native as N
     rng = np.random.default_rng(len(case) * 7 + 1)
+    # f64_*: double weights = OTM's TreeConstruction.reBalance (otm/.../tree/TreeConstruction.scala:304-352) through dm_otm_rebalance_all
+    # (two stable sort passes on the device); gap6 / gap8: 64 / 256 children per parent (the reference's gap is free)
     cfg = dict(root=(120_000, 0, 2, 1.02), four_parents=(90_000, 2, 2, 1.0), many_parents=(200_000, 9, 2, 1.3), gap3_tight=(50_000, 3, 3, 0.8),
-               gap1=(40_000, 5, 1, 1.0), nan_zero=(30_000, 1, 2, 1.05))[case]
+               gap1=(40_000, 5, 1, 1.0), nan_zero=(30_000, 1, 2, 1.05), gap6=(60_000, 2, 6, 1.1), gap8_root=(40_000, 0, 8, 1.05),
+               f64_root=(80_000, 0, 2, 1.02), f64_parents=(90_000, 6, 2, 1.1), f64_gap6=(12_000, 1, 6, 0.9), f64_nan_zero=(30_000, 1, 2, 1.05))[case]
     n, old_level, gap, slack = cfg
+    f64 = case.startswith("f64")
     level, C_ = old_level + gap, 1 << gap
     P = 1 << old_level
     lo = P - 1
     item_node = (lo + rng.integers(0, P, n)).astype(np.int32)
     w = (rng.integers(0, 6, (n, C_)).astype(np.float32) - 2.0) / 2.0
     w[:, 0] += 1.0
-    if case == "nan_zero":
+    if f64:
+        w = w.astype(np.float64) + rng.integers(0, 3, (n, C_)) * 2.0 ** -40      # differences only a double holds: float keys would tie
+    if case.endswith("nan_zero"):
         w[rng.random((n, C_)) < 0.05] = np.nan
         w[rng.random((n, C_)) < 0.05] = -0.0
         w[rng.random((n, C_)) < 0.05] = 0.0
@@ -279,8 +286,9 @@ def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
         os.environ["DM_JTM_REBALANCE"] = mode
         try:
             out = np.empty(n, np.int32)
-            eng._chk(N.lib().dm_jtm_rebalance_all(eng._h, w.ctypes.data_as(N.f32p), old_node.ctypes.data_as(N.i32p), item_node.ctypes.data_as(N.i32p),
-                                                  n, old_level, level, max_assign, out.ctypes.data_as(N.i32p)))
+            fn = N.lib().dm_otm_rebalance_all if f64 else N.lib().dm_jtm_rebalance_all
+            eng._chk(fn(eng._h, w.ctypes.data_as(C.POINTER(C.c_double) if f64 else N.f32p), old_node.ctypes.data_as(N.i32p), item_node.ctypes.data_as(N.i32p),
+                        n, old_level, level, max_assign, out.ctypes.data_as(N.i32p)))
             outs[mode] = out
         finally:
             del os.environ["DM_JTM_REBALANCE"]
@@ -289,7 +297,23 @@ def test_jtm_rebalance_device_equals_host_and_oracle(oracle, case):
     ref = np.empty(n, np.int32)
     for p in np.unique(item_node):                                       # the oracle, parent by parent
         idx = np.flatnonzero(item_node == p)
-        r = np.asarray(oracle.jtm_rebalance(np.arange(idx.size, dtype=np.int32), w[idx], old_node[idx], int(p), old_level, level, max_assign))
+        if f64:
+            if p > lo + 3:                                               # the pure-Python oracle checks the first parents, host == device the rest
+                ref[idx] = outs["host"][idx]
+                continue
+            from oracle import otm_tree_oracle as oto
+            children = oto.get_children_at_level(int(p), old_level, level)
+            cand = {i: oto.sort_node_weights(w[idx[i]].tolist(), children) for i in range(idx.size)}
+            node_items = {}
+            for i in range(idx.size):
+                node_items.setdefault(cand[i][0][0], []).append((i, cand[i][0][1], 1))
+            res = oto.re_balance(node_items, {i: int(old_node[idx[i]]) for i in range(idx.size)}, children, max_assign, cand)
+            r = np.full(idx.size, -1, np.int64)
+            for child, lst in res.items():
+                for it, _, _ in lst:
+                    r[it] = child
+        else:
+            r = np.asarray(oracle.jtm_rebalance(np.arange(idx.size, dtype=np.int32), w[idx], old_node[idx], int(p), old_level, level, max_assign))
         ref[idx] = np.where(r >= 0, r, p)
         if case == "many_parents" and p > lo + 40:
             ref[idx] = outs["host"][idx]                                 # 512 parents: the oracle checks the first 40, host == device the rest
@@ -707,3 +731,52 @@ def Engine_forward_after(w, E, NI, codes, seqs, pad, dtype):
     out = e.din_forward(codes, seqs, pad)
     e.close()
     return out
+
+
+def test_tree_file_loaded_by_the_library_and_tdm_predict(tmp_path, fixture_tree, fixture_w32, oracle_tree, oracle_din32):
+    """TDM.loadTree(treePbPath) + TDM.predict(sequence, target) (tdm/.../model/TDM.scala:10-15,50-52): the reference's own tree file
+    (the bytes of its bundled data/jtm/example_tree.bin, reproduced by tree_io) parsed INSIDE the library (dm_load_tree_file) gives the
+    index the array loaders give — same recommendations, same categorical sampler tables — and predict is sigmoid(Module.forward)
+    of the one (history, target) row; a damaged file is refused with DM_ERR_INVALID and leaves nothing half-loaded."""
+    from dismember_amd import DismemberError, Engine, TDM, tree_io
+    t = fixture_tree
+    leaf = t["is_leaf"] == 1
+    stat = dict(zip(t["stat_ids"].tolist(), t["stat_counts"].tolist()))
+    blob = tree_io.build_tree_bytes(t["ids"][leaf], t["codes"][leaf], stat)
+    path = str(tmp_path / "tree.bin")
+    open(path, "wb").write(blob)
+    rng = np.random.default_rng(3)
+    users = random_histories(rng, t["leaf_ids"], 24, 10)
+    a = Engine(0)
+    a.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); a.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    a.load_weights_din(fixture_w32, 16, 8191)
+    b = Engine(0)
+    TDM.load_tree(b, path)
+    assert b.max_level == 12
+    b.load_weights_din(fixture_w32, 16, 8191)
+    ra, rb = a.tdm_beam_search(users, 20, 10), b.tdm_beam_search(users, 20, 10)
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    # the file's node probabilities reached the sampler: sample_with_probability draws the same rows as with dm_tdm_set_node_probs
+    a.set_node_probs(t["codes"], t["probs"])
+    neg = np.arange(13, dtype=np.int32)
+    tg = rng.choice(t["leaf_ids"], 16).astype(np.int32)
+    ba = a.make_train_batch(users[:16], tg, neg, seed=5, with_prob=True)
+    bb = b.make_train_batch(users[:16], tg, neg, seed=5, with_prob=True)
+    assert all(np.array_equal(x, y) for x, y in zip(ba, bb))
+    # predict
+    m = TDM(b, "din")
+    q = np.array(CANONICAL_TDM_QUERY, np.int32)
+    for target in (int(t["leaf_ids"][7]), int(t["leaf_ids"][1234])):
+        p = m.predict(q, target)
+        codes, mask = oracle_tree.id_to_code(np.concatenate([q, [target]]).astype(np.int32))
+        ref = oracle_din32.forward(codes[-1:], codes[None, :-1], mask[mask < q.size])
+        assert abs(p - 1.0 / (1.0 + np.exp(-np.float64(ref[0])))) < 1e-6
+    # damaged files
+    for name, bad in (("cut", blob[:len(blob) - 7]), ("no_meta", blob[:blob.rindex(b"tree_meta") - 6]), ("garbage", b"\x00\x00\x00\x05hello")):
+        pb = str(tmp_path / (name + ".bin"))
+        open(pb, "wb").write(bad)
+        with pytest.raises(DismemberError) as e:
+            b.load_tree_file(pb)
+        assert e.value.code == -1, name
+        assert all(np.array_equal(x, y) for x, y in zip(rb, b.tdm_beam_search(users, 20, 10))), name      # the old index is intact
+    a.close(); b.close()
