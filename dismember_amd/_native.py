@@ -9,7 +9,8 @@ import shutil
 import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libdismember_hip.so")
+# DM_LIB_PATH: a probe / development build of the same library (tools/build_probe.sh) instead of the in-tree product build
+LIB_PATH = os.environ.get("DM_LIB_PATH") or os.path.join(_DIR, "libdismember_hip.so")
 SRC_DIR = os.path.join(_DIR, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_DIR), "include")
 

@@ -21,12 +21,21 @@
 #include <string>
 #include <vector>
 
+// Development builds (tools/build_probe.sh DM_DEV_LIGHT ...): only the E = 128 instances of the kernel templates are compiled — a third of
+// the compile time while iterating on one kernel.  Never the product build: models of other embedding sizes fail with "unsupported".
+#ifdef DM_DEV_LIGHT
+#define DM_IF_ALL_E(...)
+#else
+#define DM_IF_ALL_E(...) __VA_ARGS__
+#endif
+
 #include "beam_kernel.hip.inc"
 #include "beam_kernel_w.hip.inc"
 #include "beam_kernel_f64.hip.inc"
 #include "rows_kernel.hip.inc"
 #include "train_kernel.hip.inc"
 #include "dr_kernel.hip.inc"
+#include "dr_sliced.hip.inc"
 
 #define DM_VERSION 100
 
@@ -856,8 +865,8 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
     q.num_index = h->num_index; q.codes = d_codes; q.seqs = d_seqs; q.rowmask = d_rowmask; q.B = B; q.L = L; q.out = d_out;
     q.sm_scale = sm_scale32(h);
     switch (h->embed) {
-      case 32: return launch_rows_split_E<32>(h, q);
-      case 64: return launch_rows_split_E<64>(h, q);
+      DM_IF_ALL_E(case 32: return launch_rows_split_E<32>(h, q);)
+      DM_IF_ALL_E(case 64: return launch_rows_split_E<64>(h, q);)
       case 128: return launch_rows_split_E<128>(h, q);
     }
   }
@@ -866,9 +875,9 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
   p.b2 = h->b2; p.num_index = h->num_index; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.B = B; p.L = L;
   p.out = d_out; p.sm_scale = sm_scale32(h);
   switch (h->embed) {
-    case 16: return launch_rows_E<16>(h, p);
-    case 32: return launch_rows_E<32>(h, p);
-    case 64: return launch_rows_E<64>(h, p);
+    DM_IF_ALL_E(case 16: return launch_rows_E<16>(h, p);)
+    DM_IF_ALL_E(case 32: return launch_rows_E<32>(h, p);)
+    DM_IF_ALL_E(case 64: return launch_rows_E<64>(h, p);)
     case 128: return launch_rows_E<128>(h, p);
   }
   return fail(h, DM_ERR_UNSUPPORTED, "unsupported embed size");
@@ -1258,8 +1267,8 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
       p.defer_users = (int32_t *)((char *)h->d_defer + 16);
       int rc = DM_OK;
       switch (h->embed) {
-        case 32: rc = launch_beam_w_E<32>(h, p, pl); break;
-        case 64: rc = launch_beam_w_E<64>(h, p, pl); break;
+        DM_IF_ALL_E(case 32: rc = launch_beam_w_E<32>(h, p, pl); break;)
+        DM_IF_ALL_E(case 64: rc = launch_beam_w_E<64>(h, p, pl); break;)
         default: rc = launch_beam_w_E<128>(h, p, pl); break;
       }
       if (rc != DM_OK) return rc;
@@ -1288,24 +1297,24 @@ static int launch_beam(dm_ctx *h, BeamParams &p, const SearchPlan &pl) {
       p2.defer_count = nullptr; p2.defer_users = nullptr;
       h->ev_next_kind = 1;
       switch (h->embed) {
-        case 32: rc = launch_beam_E<32, true>(h, p2, pl2); break;
-        case 64: rc = launch_beam_E<64, true>(h, p2, pl2); break;
+        DM_IF_ALL_E(case 32: rc = launch_beam_E<32, true>(h, p2, pl2); break;)
+        DM_IF_ALL_E(case 64: rc = launch_beam_E<64, true>(h, p2, pl2); break;)
         default: rc = launch_beam_E<128, true>(h, p2, pl2); break;
       }
       h->ev_next_kind = 0;
       return rc;
     }
     switch (h->embed) {
-      case 32: return launch_beam_E<32, true>(h, p, pl);
-      case 64: return launch_beam_E<64, true>(h, p, pl);
+      DM_IF_ALL_E(case 32: return launch_beam_E<32, true>(h, p, pl);)
+      DM_IF_ALL_E(case 64: return launch_beam_E<64, true>(h, p, pl);)
       case 128: return launch_beam_E<128, true>(h, p, pl);
     }
     return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size of 32, 64 or 128");
   }
   switch (h->embed) {
-    case 16: return launch_beam_E<16, false>(h, p, pl);
-    case 32: return launch_beam_E<32, false>(h, p, pl);
-    case 64: return launch_beam_E<64, false>(h, p, pl);
+    DM_IF_ALL_E(case 16: return launch_beam_E<16, false>(h, p, pl);)
+    DM_IF_ALL_E(case 32: return launch_beam_E<32, false>(h, p, pl);)
+    DM_IF_ALL_E(case 64: return launch_beam_E<64, false>(h, p, pl);)
     case 128: return launch_beam_E<128, false>(h, p, pl);
   }
   return fail(h, DM_ERR_UNSUPPORTED, "unsupported embed size");
@@ -1845,6 +1854,14 @@ extern "C" int dm_debug_dr_slow_layers(dm_handle_t h, unsigned long long *out, i
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_rows + 2, 8, hipMemcpyDeviceToHost));
   if (reset) HIPCHK(h, hipMemset(h->d_rows + 2, 0, 8));
+  return DM_OK;
+}
+// debug: user-layers the one-wave cut of the sliced Deep-Retrieval search handed to the block version
+extern "C" int dm_debug_dr_wave_fallbacks(dm_handle_t h, unsigned long long *out, int reset) {
+  if (!h || !out) return DM_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_rows + 5, 16, hipMemcpyDeviceToHost));      // out[0] = count, out[1] = per-reason byte counters
+  if (reset) HIPCHK(h, hipMemset(h->d_rows + 5, 0, 16));
   return DM_OK;
 }
 int dm_last_scored_rows(dm_handle_t h, int64_t *rows) {

@@ -19,6 +19,16 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.fixture(autouse=True, params=["one_kernel", "sliced"])
+def dr_search_path(request):
+    """Every test runs twice: with the one-workgroup-per-user kernel (what a batch below 512 users takes) and with the column-sliced
+    pipeline of dr_sliced.hip.inc forced onto these small batches (DM_DR_SLICED_MIN_USERS is read at model load)."""
+    if request.param == "sliced":
+        os.environ["DM_DR_SLICED_MIN_USERS"] = "1"
+    yield request.param
+    os.environ.pop("DM_DR_SLICED_MIN_USERS", None)
+
+
 def make(K, D, L, E, num_item, seed, dtype, scale=0.3, J=2, with_paths=True, collapse=False):
     from dismember_amd import Engine
     from oracle import pyoracle as po
@@ -213,3 +223,40 @@ def test_split_history_gemm_vs_fp32_gemm():
             assert abs(path_prob(orc, seqs[u], p1[u, q]) - v1[u, q]) <= 1e-4 * v1[u, q] + 1e-30
     assert same >= 0.95 * len(seqs), same
     assert not np.array_equal(v0, v1)        # the two GEMMs really are different kernels
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sliced_pipeline_equals_one_kernel_on_a_batch(dtype, dr_search_path):
+    """600 users (above the default switch-over of 512), BASELINE config 5's shape: the column-sliced pipeline — history factors and
+    tabulated table factors instead of one exp per candidate, one-wave cuts — returns the paths of dr_beam_kernel for every user and
+    its probabilities to rounding (fp64: 1e-12; the two differ in the summation order of the softmax denominators only)."""
+    if dr_search_path == "sliced":
+        pytest.skip("the batch takes the sliced pipeline by its size; the forced variant adds nothing")
+    from dismember_amd import Engine
+    rng = np.random.default_rng(21)
+    K, D, L, E, n, beam, U = 1000, 3, 10, 32, 5000, 50, 600
+    w = synth.make_dr_model(n, K, D, L, E, rng, scale=0.05)
+    seqs = histories(rng, U, L, n)
+    seqs[1] = seqs[2]                                   # identical users: identical results
+    out = {}
+    for mode in ("sliced", "one_kernel"):
+        if mode == "one_kernel":
+            os.environ["DM_DR_SLICED"] = "0"
+        try:
+            eng = Engine(0)
+            eng.dr_load_model(w, E, L, K, D, n, dtype=dtype)
+            out[mode] = eng.dr_beam_search(seqs, beam)
+            eng.close()
+        finally:
+            os.environ.pop("DM_DR_SLICED", None)
+    (pa, pra, ca), (pb, prb, cb) = out["sliced"], out["one_kernel"]
+    assert np.array_equal(ca, cb) and (ca == beam).all()
+    same = (pa == pb).all(axis=(1, 2))
+    if dtype == np.float64:
+        assert same.all(), int((~same).sum())
+        np.testing.assert_allclose(pra, prb, rtol=1e-12, atol=0)
+    else:
+        assert same.mean() > 0.9                          # f32: near-ties at the cut may flip between two summation orders
+        np.testing.assert_allclose(pra[same], prb[same], rtol=2e-5, atol=0)
+    assert np.array_equal(pa[1], pa[2]) and np.array_equal(pra[1], pra[2])
+    assert (np.diff(pra, axis=1) <= 0).all()

@@ -50,10 +50,24 @@ def main():
     nl, ms = eng.timing_get()
     out["beam_search"] = {"users_per_s": U * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_ms_per_step": ms / a.steps,
                           "launches_per_step": nl / a.steps}
+    per = {}
+    for kind, name in ((0, "gemm / single kernel"), (11, "layer0"), (12, "stats_d1"), (13, "select_d1"), (14, "stats_d2"), (15, "select_d2"), (23, "select_d1_todo_pass"), (25, "select_d2_todo_pass")):
+        n_, ms_ = eng.timing_get_kind(kind)
+        if n_:
+            per[name] = round(ms_ / a.steps, 4)
+    out["beam_search"]["kernel_ms_by_launch"] = per
     slow = C.c_ulonglong(0)
     N.lib().dm_debug_dr_slow_layers.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     N.lib().dm_debug_dr_slow_layers(eng._h, C.byref(slow), 1)
     out["beam_search"]["exact_path_layers_per_user"] = slow.value / float(U * (a.steps + 1))
+    try:
+        N.lib().dm_debug_dr_wave_fallbacks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+        two = (C.c_ulonglong * 2)()
+        N.lib().dm_debug_dr_wave_fallbacks(eng._h, two, 1)
+        out["beam_search"]["wave_cut_fallback_layers_per_user"] = two[0] / float(U * (a.steps + 1))
+        out["beam_search"]["wave_cut_fallback_reasons_hex"] = hex(two[1])      # bytes: [1] degenerate sums, [2] score floor, [3] blocks, [4] too few, [5] too many
+    except AttributeError:
+        pass
     if a.rerank:
         t0 = time.perf_counter()
         pi = synth.dr_path_items_fast(synth.make_dr_paths(a.items, K, D, 2, rng), K)
