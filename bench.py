@@ -734,6 +734,34 @@ def main():
             sync(); barrier()
             dtb = max_over_ranks(time.perf_counter() - t0)
             _, kms_b = eng.timing_get()
+            # per launch (HIP events on the kernels' stream): kind 0 = the history GEMM, 11 = layer 0, 10 + 2d / 11 + 2d = statistics / cut of layer d
+            per_launch = {}
+            for kind_, name_ in ((0, "history_gemm"), (11, "layer0"), (12, "stats_layer1"), (13, "cut_layer1"), (14, "stats_layer2"), (15, "cut_layer2"),
+                                 (21, "layer0_flagged_users"), (23, "cut_layer1_flagged_users"), (25, "cut_layer2_flagged_users")):
+                n_, ms_ = eng.timing_get_kind(kind_)
+                if n_:
+                    per_launch[name_] = ms_ / nsd
+            esz_ = 8 if tag == "f64" else 4
+            gemm_ms = per_launch.get("history_gemm", 0.0)
+            st_ms = per_launch.get("stats_layer1", 0.0) + per_launch.get("stats_layer2", 0.0)
+            # algorithmic work per launch: the history GEMM's 2 D K L E flops per user on the matrix pipe; the statistics kernels' factor rows —
+            # per user and layer d: one ES row slice set (K values) + beam x d table rows of K values, read through the XCDs' L2s
+            gemm_flops = 2.0 * Dd * Kd * Ld * Ed * Ud
+            st_bytes = sum((1 + beam_d * d_) * Kd * esz_ for d_ in range(1, Dd)) * float(Ud)
+            peak_mm = 78.6 if tag == "f64" else (2516.6 / 3.0)            # fp64 MFMA; split-fp16: three fp16 MFMAs per product
+            rl = {}
+            if gemm_ms > 0:
+                rl["roofline"] = {"bound": "mfma", "kernel": "dr_gemm_kernel<double>" if tag == "f64" else "dr_gemm_split_kernel",
+                                  "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": peak_mm, "unit": "TFLOP/s",
+                                  "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak_mm, "kernel_ms_avg": gemm_ms, "traffic": None,
+                                  "flops_per_user": 2 * Dd * Kd * Ld * Ed,
+                                  "note": "the dominant kernel of the search (%.0f %% of the kernel time)" % (100.0 * gemm_ms / max(kms_b / nsd, 1e-9))}
+            if st_ms > 0:
+                rl["roofline_statistics_kernels"] = {"bound": "l2", "kernel": "drs_stats_kernel<%s, 1> + <%s, 2>" % (("double",) * 2 if tag == "f64" else ("float",) * 2),
+                                                     "achieved": st_bytes / (st_ms * 1e-3) / 1e9, "peak": 34500.0, "unit": "GB/s",
+                                                     "frac": st_bytes / (st_ms * 1e-3) / 1e9 / 34500.0, "kernel_ms": st_ms, "bytes_per_user": st_bytes / Ud,
+                                                     "note": "factor rows read through the eight XCD L2s (aggregate L2 peak, MI355X_MICROARCH.md); the tables' "
+                                                             "column slices are L2-resident by construction (88 % TCC hits, profiles/r04_dr_*)"}
             paths_h = np.empty((Ud, beam_d, Dd), np.int32)
             eng.d2h(paths_h, q_paths)
             eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
@@ -745,7 +773,8 @@ def main():
             dtr = max_over_ranks(time.perf_counter() - t0)
             runs[tag] = {"beam_search_users_per_s": world * Ud * nsd / dtb, "beam_search_ms_per_step": dtb / nsd * 1e3,
                          "beam_search_kernel_ms_per_step": kms_b / nsd, "recommend_users_per_s": world * Ud * nsd / dtr,
-                         "paths": paths_h}
+                         "kernel_ms_by_launch": per_launch, "paths": paths_h}
+            runs[tag].update(rl)
             eng.close()
         eng = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))       # the later sections expect a live engine to close
         same_paths = int((runs["f64"]["paths"] == runs["f32"]["paths"]).all(axis=(1, 2)).sum())
