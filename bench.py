@@ -826,18 +826,21 @@ def main():
             oc6[orng.random((Uo6, L)) < 0.15] = -1
             d_s6 = eng.dev_alloc(Uo6 * L * 4); d_i6 = eng.dev_alloc(Uo6 * 2 * a.beam * 4); d_c6 = eng.dev_alloc(Uo6 * 2 * a.beam * 4); d_n6 = eng.dev_alloc(Uo6 * 4)
             eng.h2d(d_s6, oc6)
-            eng.otm_beam_search_dev(d_s6, 2048, L, a.beam, depth6, d_i6, d_c6, d_n6)
+            eng.otm_beam_search_dev(d_s6, Uo6, L, a.beam, depth6, d_i6, d_c6, d_n6)      # warm-up at full size (first touch of the 34 GB table)
             sync(); eng.timing_reset(); barrier()
             t0 = time.perf_counter()
-            eng.otm_beam_search_dev(d_s6, Uo6, L, a.beam, depth6, d_i6, d_c6, d_n6)
+            calls6 = 3
+            for _ in range(calls6):
+                eng.otm_beam_search_dev(d_s6, Uo6, L, a.beam, depth6, d_i6, d_c6, d_n6)
             sync(); barrier()
-            dt6 = max_over_ranks(time.perf_counter() - t0)
+            dt6 = max_over_ranks(time.perf_counter() - t0) / calls6
             nl6, kms6 = eng.timing_get()
-            rows6 = eng.last_scored_rows()
+            kms6 = kms6 / max(nl6, 1)                      # average per launch
+            rows6 = eng.last_scored_rows()                 # of the last call
             fl6 = rows6 * 2.0 * (E * E + 2 * L * E + E)
             otm64 = {"workload": "OTM beam-search serving in fp64 (the reference's DIN[Double]): complete depth-%d tree (%d nodes x %d doubles = %.1f GB), "
                                  "beam=%d, request and results resident in HBM" % (depth6, ni6, E, ni6 * E * 8 / 1e9, a.beam),
-                     "scorer": eng.scorer_mode()["mode"], "kernel": eng.last_beam_kernel(), "users_per_call": Uo6,
+                     "scorer": eng.scorer_mode()["mode"], "kernel": eng.last_beam_kernel(), "users_per_call": Uo6, "calls_timed": calls6,
                      "users_per_s": world * Uo6 / dt6, "kernel_ms": kms6, "scored_rows_per_user": rows6 / Uo6,
                      "roofline": {"bound": "mfma", "dtype": "f64", "achieved": fl6 / (kms6 * 1e-3) / 1e12 if kms6 else None, "peak": 78.6,
                                   "unit": "TFLOP/s", "frac": (fl6 / (kms6 * 1e-3) / 78.6e12) if kms6 else None,

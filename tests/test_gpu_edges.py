@@ -124,16 +124,23 @@ def test_full_size_properties_config2():
     eng.close()
 
 
-def test_full_size_properties_config5():
-    """BASELINE config 5 at full size (Deep-Retrieval D=3, K=1000, beam 50, E=128, 10M items, f32)."""
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_full_size_properties_config5(dtype):
+    """BASELINE config 5 at full size (Deep-Retrieval D=3, K=1000, beam 50, E=128, 10M items) as an f32 model and in the
+    reference's own fp64 (deep-retrieval/.../model/LayerModel.scala:68-84 runs in Double).  A 256-user call takes the
+    one-kernel beam search, a 1 024-user call the column-sliced pipeline (dr_sliced.hip.inc): the same users must come back
+    with the same paths from both — bit for bit in fp64."""
     from dismember_amd import Engine
     E, L, K, D, items, beam, U = 128, 10, 1000, 3, 10_000_000, 50, 256
+    dt = np.float32 if dtype == "f32" else np.float64
+    rel = 1e-5 if dtype == "f32" else 1e-12
     eng = Engine(0)
-    eng.dr_load_model_synthetic(E, L, K, D, items, synth.SEED, scale=0.05, rerank=False)
+    eng.dr_load_model_synthetic(E, L, K, D, items, synth.SEED, scale=0.05, rerank=False, dtype=dt)
     rng = np.random.default_rng(9)
-    seqs = rng.integers(0, items, size=(U, L)).astype(np.int32)
-    seqs[rng.random((U, L)) < 0.2] = -1
-    seqs[0] = -1
+    big = rng.integers(0, items, size=(4 * U, L)).astype(np.int32)
+    big[rng.random((4 * U, L)) < 0.2] = -1
+    big[0] = -1
+    seqs = big[:U]
     p, pr, cnt = eng.dr_beam_search(seqs, beam)
     p2, pr2, _ = eng.dr_beam_search(seqs, beam)
     assert np.array_equal(p, p2) and np.array_equal(pr, pr2)
@@ -141,13 +148,22 @@ def test_full_size_properties_config5():
     assert (np.diff(pr, axis=1) <= 0).all() and (pr > 0).all() and (pr.sum(axis=1) <= 1 + 1e-5).all()
     codes = (p[..., 0].astype(np.int64) * K + p[..., 1]) * K + p[..., 2]
     assert all(len(set(row.tolist())) == beam for row in codes)
+    # the sliced pipeline (>= 512 users per call) against the one-kernel search on the same users
+    pb, prb, cb = eng.dr_beam_search(big, beam)
+    assert (cb == beam).all()
+    if dtype == "f64":
+        assert np.array_equal(pb[:U], p) and np.array_equal(prb[:U], pr)
+    else:
+        same = (pb[:U] == p).all(axis=(1, 2))
+        assert same.mean() >= 0.9, same.mean()
+        assert np.allclose(prb[:U][same], pr[same], rtol=1e-4)
     # prefix property: the top path of a wider beam is at least as probable; a beam of 1 is the greedy path
     g, gp, _ = eng.dr_beam_search(seqs[:32], 1)
     w, wp, _ = eng.dr_beam_search(seqs[:32], 4 * beam)
-    assert (wp[:, 0] >= pr[:32, 0] * (1 - 1e-5)).all() and (pr[:32, 0] >= gp[:, 0] * (1 - 1e-5)).all()
+    assert (wp[:, 0] >= pr[:32, 0] * (1 - rel)).all() and (pr[:32, 0] >= gp[:, 0] * (1 - rel)).all()
     # the beam's own best path contains the greedy first node whenever the greedy path is the best path
     same = (g[:, 0, :] == p[:32, 0, :]).all(axis=1)
-    assert np.allclose(gp[same, 0], pr[:32][same, 0], rtol=1e-5)
+    assert np.allclose(gp[same, 0], pr[:32][same, 0], rtol=max(rel, 1e-12))
     eng.close()
 
 
