@@ -1352,14 +1352,27 @@ static void fill_common(dm_ctx *h, BeamParams &p) {
   p.next_user = h->d_rows + 1;
 }
 
+static int tdm_pipeline_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, const dm_tdm_search_opts *o, int max_beam,
+                            const int64_t *d_coff, const int32_t *d_cids, int32_t *d_ids, float *d_scores, int32_t *d_counts,
+                            int trace_levels, int cap, int32_t *d_tc, float *d_ts, int32_t *d_tn);
+
 static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, const dm_tdm_search_opts *o, int max_beam,
                           const int64_t *d_coff, const int32_t *d_cids, int32_t *d_ids, float *d_scores, int32_t *d_counts,
                           int trace_levels, int32_t *d_tc, float *d_ts, int32_t *d_tn, bool *direct = nullptr) {
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "tdm beam search: tree, id maps and weights must be loaded first");
-  if (U < 0 || L <= 0 || L > DM_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..16)");
+  if (U < 0 || L <= 0 || L > DM_PIPE_MAXL || !o || o->beam <= 0 || o->topk <= 0) return fail(h, DM_ERR_INVALID, "tdm beam search: bad arguments (L must be 1..32)");
   if (U == 0) return DM_OK;          // an empty batch is not an error
   if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: tree codes exceed the embedding table (embeddingLookup would fail)");
   if (h->max_code >= h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: id map codes exceed the embedding table");
+  if (L > DM_MAXL) {
+    // histories of 17 .. 32 positions: the per-level pipeline (tdm_pipeline.hip.inc); the fused kernels hold one 16-position score tile
+    if (direct) { *direct = false; return DM_OK; }          // (the caller takes the staged path and comes back)
+    HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
+    const int cap_ = ((2 * max_beam + 15) / 16) * 16 < 32 ? 32 : ((2 * max_beam + 15) / 16) * 16;
+    return tdm_pipeline_dev(h, d_seq, U, L, o, max_beam, d_coff, d_cids, d_ids, d_scores, d_counts, trace_levels, cap_, d_tc, d_ts, d_tn);
+  }
   int start, level;
   level_start_int(o->beam, &start, &level);
   int n_levels = h->max_level - level + 1;
@@ -1587,8 +1600,8 @@ static int otm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, int
 
 static int otm_check(dm_ctx *h, int64_t U, int L, int beam, int leaf_level, const char *who) {
   if (!h->w_loaded) return fail(h, DM_ERR_STATE, std::string(who) + ": weights not loaded");
-  if (U < 0 || L <= 0 || L > DM_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
-    return fail(h, DM_ERR_INVALID, std::string(who) + ": bad arguments");
+  if (U < 0 || L <= 0 || L > DM_PIPE_MAXL || beam <= 0 || leaf_level <= 0 || leaf_level > 30)
+    return fail(h, DM_ERR_INVALID, std::string(who) + ": bad arguments (L must be 1..32)");
   if ((((int64_t)1) << (leaf_level + 1)) - 1 > h->num_index) return fail(h, DM_ERR_INDEX, std::string(who) + ": leaf level exceeds the embedding table");
   return DM_OK;
 }
@@ -1603,7 +1616,7 @@ int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U,
   if (U == 0) return DM_OK;
   if (!d_seq_codes || !d_out_node_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
-  if (use_f64_beam(h)) {
+  if (use_f64_beam(h) || L > DM_MAXL) {      // (histories of 17 .. 32 positions: the per-level pipeline in the model's type)
     return otm64_search_dev(h, d_seq_codes, U, L, beam, leaf_level, d_out_node_ids, nullptr, d_out_scores, d_out_counts, 0, 0, nullptr,
                             nullptr, nullptr, nullptr);
   }
@@ -1665,7 +1678,7 @@ static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
-  if (use_f64_beam(h))      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
+  if (use_f64_beam(h) || L > DM_MAXL)      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, 0, nullptr, nullptr, nullptr, nullptr);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, 0, nullptr, nullptr, nullptr);
 }
@@ -1675,7 +1688,7 @@ int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U,
                              int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
   if (!h) return DM_ERR_INVALID;
   if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_trace: bad trace arguments");
-  if (use_f64_beam(h))
+  if (use_f64_beam(h) || L > DM_MAXL)
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, max_levels, trace_codes,
                              nullptr, trace_scores, trace_counts);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, max_levels, trace_codes,
@@ -1774,6 +1787,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "sampler.hip.inc"
 #include "dr_host.hip.inc"
 #include "otm64.hip.inc"
+#include "tdm_pipeline.hip.inc"
 #include "comm.hip.inc"
 #include "jtm_sharded.hip.inc"
 #include "otm_train.hip.inc"

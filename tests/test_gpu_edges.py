@@ -1,4 +1,4 @@
-"""Edge cases and full-size properties (GPU): empty batches, history lengths 1..16, extreme beams, and — at BASELINE.json's
+"""Edge cases and full-size properties (GPU): empty batches, history lengths 1..32, extreme beams, and — at BASELINE.json's
 config-2 / config-5 sizes, where the CPU oracle cannot follow — properties that do not depend on the size."""
 import os
 
@@ -57,7 +57,97 @@ def test_history_lengths_1_to_16(oracle, E, L):
             assert (np.abs(sc[u, :cnt[u]] - osc) <= ATOL + RTOL * np.abs(osc)).all()
     assert same >= len(seqs) - 1, same
     with pytest.raises(Exception):
-        eng.tdm_beam_search(np.zeros((1, 17), np.int32), beam, 20)       # L > 16: DM_ERR_INVALID, not a wrong answer
+        eng.tdm_beam_search(np.zeros((1, 33), np.int32), beam, 20)       # L > 32: DM_ERR_INVALID, not a wrong answer
+    eng.close()
+
+
+@pytest.mark.parametrize("E,L", [(128, 17), (128, 24), (128, 32), (32, 20)])
+def test_history_lengths_17_to_32_tdm(oracle, E, L):
+    """Histories longer than the fused kernels' 16-position score tile take the per-level pipeline (csrc/tdm_pipeline.hip.inc);
+    the reference has no length limit (scalann/.../nn/Attention.scala:34-53).  Same contract as every TDM search: the oracle's
+    integer logic replayed exactly on the device's per-level scores, scores within the fp32 tolerance — on a ragged tree, with
+    and without the mask, and with consumed items widening the beam (Recommender.recommendItems, Recommender.scala:18-37)."""
+    from test_gpu_parity import replay_and_check
+    rng = np.random.default_rng(1000 * E + L)
+    depth, n_items, beam = 9, 400, 24
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
+    odin = oracle.Din(w, E, L, NI)
+    eng = _engine(t, w, E)
+    seqs = random_histories(rng, t["leaf_ids"], 19, L, pad_prob=0.3)
+    seqs[0] = 0                                           # all padding
+    seqs[1, :] = seqs[1, 0]                               # one item repeated L times
+    for use_mask in (True, False):
+        replay_and_check(otree, odin, eng, seqs, beam, 20, use_mask=use_mask)
+    assert "pipeline" in eng.last_beam_kernel()
+    replay_and_check(otree, odin, eng, seqs[:5], 300, 50)             # a beam wider than any level of the tree
+    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, 20)
+    same = 0
+    for u in range(len(seqs)):
+        oi, osc = otree.recommend(odin, seqs[u], 20, beam)
+        if ids[u, :cnt[u]].tolist() == oi.tolist():
+            same += 1
+            assert (np.abs(sc[u, :cnt[u]] - osc) <= ATOL + RTOL * np.abs(osc)).all()
+    assert same >= len(seqs) - 1, same
+    # one user per call (the serving loop's entry: the host-mapped path hands over to the pipeline)
+    i1, s1, c1 = eng.tdm_beam_search(seqs[3:4], beam, 20)
+    assert np.array_equal(i1[0], ids[3]) and np.array_equal(s1[0], sc[3]) and c1[0] == cnt[3]
+    # consumed items: dropped from the result, and a long list widens the beam
+    consumed = [np.unique(rng.choice(t["leaf_ids"], 60)).tolist() if u % 2 else ids[u, :5].tolist() for u in range(len(seqs))]
+    idc, scc, cntc = eng.tdm_beam_search(seqs, beam, 20, consumed=consumed, widen_consumed=True)
+    agree = 0
+    for u in range(len(seqs)):
+        ref = otree.recommend_items(odin, seqs[u], 20, beam, consumed=consumed[u])
+        assert cntc[u] == len(ref)
+        assert not set(idc[u, :cntc[u]].tolist()) & set(consumed[u])
+        agree += int(np.array_equal(idc[u, :cntc[u]], ref))
+    assert agree >= len(seqs) - 1, agree
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,E,L,beam", [("f64", 128, 17, 33), ("f64", 64, 32, 100), ("f32", 128, 24, 33), ("f32", 128, 32, 7)])
+def test_history_lengths_17_to_32_otm(oracle, dtype, E, L, beam):
+    """OTM searches with 17..32 history positions run the per-level pipeline in the model's own type (csrc/otm64.hip.inc):
+    buildBeamNodes (otm/.../model/CandidateSearcher.scala:109-122) replayed exactly on the device's scores; fp64 models: node
+    lists equal to the fp64 oracle's and scores within 1e-10 / 1e-9; f32 models: scores within the fp32 tolerance."""
+    from dismember_amd import Engine
+    from test_gpu_precision import _otm_replay
+    leaf_level, U = 9, 7
+    rng = np.random.default_rng(E + beam + L)
+    NI = (1 << (leaf_level + 1)) - 1
+    w64 = random_din_weights(rng, E, NI, dtype=np.float64)
+    w = w64 if dtype == "f64" else w64.astype(np.float32)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    codes = rng.integers((1 << leaf_level) - 1, NI, (U, L)).astype(np.int32)
+    codes[rng.random((U, L)) < 0.25] = -1
+    codes[0] = -1
+    start_level = beam.bit_length() - 1
+    levels = leaf_level - start_level
+    odin = oracle.Din(w.astype(np.float64), E, L, NI)
+    if dtype == "f64":
+        ids, sc, cnt, tc, ts, tn = eng.otm_beam_search_f64(codes, beam, leaf_level, trace_levels=levels)
+        tol = (1e-10, 1e-9)
+    else:
+        ids, sc, cnt, tc, ts, tn = eng.otm_beam_search_trace(codes, beam, leaf_level, levels)
+        tol = (ATOL, RTOL)
+    assert "pipeline" in eng.last_beam_kernel()
+    _otm_replay(oracle, tc, ts, tn, beam, start_level, leaf_level, ids)
+    for u in range(U):
+        for it in range(levels):
+            n = int(tn[u, it])
+            pad = np.flatnonzero(np.tile(codes[u] < 0, n)).astype(np.int32)
+            ref = odin.forward(tc[u, it, :n], np.tile(codes[u], (n, 1)), pad)
+            assert (np.abs(ts[u, it, :n] - ref) <= tol[0] + tol[1] * np.abs(ref)).all(), (u, it)
+        if dtype == "f64":
+            oi, osc = oracle.otm_beam_search(odin, codes[u], leaf_level, beam)
+            assert np.array_equal(ids[u, :cnt[u]], oi), u
+            assert (np.abs(sc[u, :cnt[u]] - osc) <= 1e-10 + 1e-9 * np.abs(osc)).all()
+    # the plain and the device-resident entry points give the traced search's lists
+    i2, s2, c2 = eng.otm_beam_search(codes, beam, leaf_level)
+    assert np.array_equal(i2, ids) and np.array_equal(c2, cnt) and np.array_equal(s2, sc.astype(np.float32))
     eng.close()
 
 
@@ -129,7 +219,7 @@ def test_full_size_properties_config5(dtype):
     """BASELINE config 5 at full size (Deep-Retrieval D=3, K=1000, beam 50, E=128, 10M items) as an f32 model and in the
     reference's own fp64 (deep-retrieval/.../model/LayerModel.scala:68-84 runs in Double).  A 256-user call takes the
     one-kernel beam search, a 1 024-user call the column-sliced pipeline (dr_sliced.hip.inc): the same users must come back
-    with the same paths from both — bit for bit in fp64."""
+    with the same paths from both — bit for bit in fp64 (probabilities within 1e-9 relative)."""
     from dismember_amd import Engine
     E, L, K, D, items, beam, U = 128, 10, 1000, 3, 10_000_000, 50, 256
     dt = np.float32 if dtype == "f32" else np.float64
@@ -152,14 +242,16 @@ def test_full_size_properties_config5(dtype):
     pb, prb, cb = eng.dr_beam_search(big, beam)
     assert (cb == beam).all()
     if dtype == "f64":
-        assert np.array_equal(pb[:U], p) and np.array_equal(prb[:U], pr)
+        # paths bit for bit; the probabilities carry the sliced pipeline's factorised softmax denominators (1e-9 relative, the
+        # fp64 contract of tests/test_gpu_dr.py)
+        assert np.array_equal(pb[:U], p) and np.allclose(prb[:U], pr, rtol=1e-9, atol=0)
     else:
         same = (pb[:U] == p).all(axis=(1, 2))
         assert same.mean() >= 0.9, same.mean()
         assert np.allclose(prb[:U][same], pr[same], rtol=1e-4)
     # prefix property: the top path of a wider beam is at least as probable; a beam of 1 is the greedy path
     g, gp, _ = eng.dr_beam_search(seqs[:32], 1)
-    w, wp, _ = eng.dr_beam_search(seqs[:32], 4 * beam)
+    w, wp, _ = eng.dr_beam_search(seqs[:32], (4 if dtype == "f32" else 2) * beam)     # (fp64 frontiers of 256 paths outgrow the LDS)
     assert (wp[:, 0] >= pr[:32, 0] * (1 - rel)).all() and (pr[:32, 0] >= gp[:, 0] * (1 - rel)).all()
     # the beam's own best path contains the greedy first node whenever the greedy path is the best path
     same = (g[:, 0, :] == p[:32, 0, :]).all(axis=1)

@@ -17,7 +17,10 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
 }
 
 // rows [n_rows][128] floats; second table (or null); per tile the wave's 16 rows: level l uniform in [lo, hi], node uniform in the level
-template <bool TWO>
+// PAT 0: the MFMA operand pattern (4 lanes per row: an instruction touches 16 rows x 64 B = 16 half lines);
+// PAT 1: 8 lanes per row (an instruction touches 8 rows x 128 B = 8 whole lines; the data would need a cross-lane move to become an operand)
+// PAT 2: 32 lanes per row (2 rows x 512 B per instruction)
+template <bool TWO, int PAT>
 __global__ __launch_bounds__(256) void gather_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, int lo, int hi, int tiles,
                                                      float *out) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -30,11 +33,31 @@ __global__ __launch_bounds__(256) void gather_kernel(const float4 *__restrict__ 
     return (int64_t)(first + (mix(h) & ((1ull << lv) - 1)));
   };
   auto load = [&](int t) {
-    const int64_t row = row_of(t);
+    if (PAT == 0) {
+      const int64_t row = row_of(t);
 #pragma unroll
-    for (int jc = 0; jc < 8; jc++) {
-      cur[jc] = a[row * 32 + jc * 4 + g];
-      if (TWO) cur[8 + jc] = b[row * 32 + jc * 4 + g];
+      for (int jc = 0; jc < 8; jc++) {
+        cur[jc] = a[row * 32 + jc * 4 + g];
+        if (TWO) cur[8 + jc] = b[row * 32 + jc * 4 + g];
+      }
+    } else if (PAT == 1) {
+      // instruction i = (half h, line q): rows 8h .. 8h+7, line q of the row; lane l -> row 8h + (l >> 3), 16 B at (l & 7) * 16
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int64_t row = __shfl(row_of(t), 8 * h + (lane >> 3));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          cur[h * 4 + q] = a[row * 32 + q * 8 + (lane & 7)];
+          if (TWO) cur[8 + h * 4 + q] = b[row * 32 + q * 8 + (lane & 7)];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const int64_t row = __shfl(row_of(t), 2 * h + (lane >> 5));
+        cur[h] = a[row * 32 + (lane & 31)];
+        if (TWO) cur[8 + h] = b[row * 32 + (lane & 31)];
+      }
     }
   };
   load(0);
@@ -57,7 +80,7 @@ int main(int argc, char **argv) {
   hipMemset(a, 0, n_rows * 512); hipMemset(b, 0, n_rows * 512);
   hipMalloc(&out, 256 * 256 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  struct Case { int lo, hi, two; const char *what; };
+  struct Case { int lo, hi, two; const char *what; int pat = 0; };
   const Case cases[] = {
       {8, depth, 0, "all levels, 512 B per row (today's tile)"},
       {8, depth, 1, "all levels, 1 KB per row (P table for every level)"},
@@ -65,13 +88,18 @@ int main(int argc, char **argv) {
       {8, 17, 1, "levels 8..17, 1 KB per row (P table for the cache-resident levels)"},
       {8, 12, 1, "levels 8..12, 1 KB per row (L2-resident: 8 MB)"},
       {18, depth, 0, "levels 18..depth, 512 B per row"},
+      {8, depth, 0, "all levels, 512 B per row, 8 lanes per row (whole 128-B lines)", 1},
+      {8, 17, 1, "levels 8..17, 1 KB per row, 8 lanes per row", 1},
+      {8, depth, 0, "all levels, 512 B per row, 32 lanes per row (a row per half wave)", 2},
+      {8, 17, 1, "levels 8..17, 1 KB per row, 32 lanes per row", 2},
   };
   for (const Case &c : cases) {
     const int tiles = 4000;
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(e0);
-      if (c.two) gather_kernel<true><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out);
-      else gather_kernel<false><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out);
+      if (c.pat == 0) { if (c.two) gather_kernel<true, 0><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); else gather_kernel<false, 0><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); }
+      if (c.pat == 1) { if (c.two) gather_kernel<true, 1><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); else gather_kernel<false, 1><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); }
+      if (c.pat == 2) { if (c.two) gather_kernel<true, 2><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); else gather_kernel<false, 2><<<256, 256>>>(a, b, c.lo, c.hi, tiles, out); }
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
