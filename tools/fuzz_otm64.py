@@ -21,7 +21,7 @@ for c in range(n_cfg):
     E = int(rng.choice([16, 32, 64, 128, 24, 48]))
     leaf_level = int(rng.integers(3, 11))
     beam = int(rng.integers(1, 40)) if rng.random() < 0.5 else int(rng.integers(1, 260))
-    L = int(rng.integers(1, 17))
+    L = int(rng.integers(1, int(os.environ.get("FUZZ_LMAX", "16")) + 1))        # 17 .. 32: the per-level pipeline
     U = int(rng.integers(1, 12))
     NI = (1 << (leaf_level + 1)) - 1
     w = random_din_weights(rng, E, NI, dtype=np.float64, std=float(rng.choice([0.05, 0.3])), bias_std=0.1)

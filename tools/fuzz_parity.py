@@ -31,14 +31,16 @@ for c in range(n_cfg):
     beam = int(rng.integers(1, 300)) if rng.random() < 0.5 else int(rng.integers(1, 40))      # half the sweep on small beams: one-wave teams
     topk = int(rng.integers(1, 2 * beam + 2))
     U = int(rng.integers(1, 20))
+    LMAX = int(os.environ.get("FUZZ_LMAX", "0"))                # 0: the configs' L = 10; n: L uniform in 1 .. n (17 .. 32 = the per-level pipeline)
+    L = int(rng.integers(1, LMAX + 1)) if LMAX else 10
     t = synthetic_tree(rng, depth, n_items)
     NI = (1 << (depth + 1)) - 1
     w = random_din_weights(rng, E, NI)
     otree = po.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
-    odin = po.Din(w, E, 10, NI)
+    odin = po.Din(w, E, L, NI)
     eng = make_engine(t, w, E)
     eng.set_scorer_mode(os.environ.get("DM_SCORER", "auto"))
-    seqs = random_histories(rng, t["leaf_ids"], U, 10, pad_prob=float(rng.random()) * 0.6, unknown_prob=0.05)
+    seqs = random_histories(rng, t["leaf_ids"], U, L, pad_prob=float(rng.random()) * 0.6, unknown_prob=0.05)
     try:
         um = bool(rng.integers(0, 2))
         replay_and_check(otree, odin, eng, seqs, beam, topk, use_mask=um)
@@ -54,7 +56,7 @@ for c in range(n_cfg):
         ran += 1; users += U
     except AssertionError as e:
         bad += 1
-        print("MISMATCH cfg", c, dict(E=E, depth=depth, n_items=n_items, beam=beam, topk=topk, U=U), str(e)[:300])
+        print("MISMATCH cfg", c, dict(E=E, depth=depth, n_items=n_items, beam=beam, topk=topk, U=U, L=L), str(e)[:300])
     eng.close()
 for k, v in sorted(kernels.items()):
     print("  kernel", k, v)

@@ -1,0 +1,40 @@
+"""Throughput of the per-level pipelines that serve history lengths 17 .. 32 (csrc/tdm_pipeline.hip.inc, csrc/otm64.hip.inc), beside the
+fused kernels at L = 16 on the same model:  python tools/long_history_bench.py [users=4096] [depth=20] [beam=200]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dismember_amd import Engine, synth          # noqa: E402
+
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+beam = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+E, items = 128, 1_000_000 if depth >= 20 else (1 << depth) // 2
+NI = (1 << (depth + 1)) - 1
+tree = synth.make_tree(items, depth, np.random.default_rng(synth.SEED))
+eng = Engine(0)
+eng.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth)
+eng.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+eng.load_weights_din_synthetic(E, NI, synth.SEED, tree_depth=depth, rho=0.95)
+out = {"users": U, "depth": depth, "beam": beam, "E": E}
+for L in (16, 17, 24, 32):
+    seqs = synth.make_users(tree["leaf_ids"], U, L, np.random.default_rng(5))
+    eng.tdm_beam_search(seqs[:64], beam, beam)
+    t0 = time.perf_counter()
+    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, beam)
+    dt = time.perf_counter() - t0
+    out["tdm_L%d" % L] = {"kernel": eng.last_beam_kernel(), "ms": round(dt * 1e3, 2), "users_per_s": round(U / dt), "rows": eng.last_scored_rows()}
+eng.close()
+# OTM in fp64 on a complete tree
+d6 = min(depth, 16)
+eng = Engine(0)
+eng.load_weights_din_synthetic_f64(E, (1 << (d6 + 1)) - 1, synth.SEED)
+rng = np.random.default_rng(7)
+for L in (16, 24):
+    codes = ((1 << d6) - 1 + rng.integers(0, 1 << d6, size=(U, L))).astype(np.int32)
+    eng.otm_beam_search_f64(codes[:64], beam, d6)
+    t0 = time.perf_counter()
+    eng.otm_beam_search_f64(codes, beam, d6)
+    dt = time.perf_counter() - t0
+    out["otm_f64_L%d" % L] = {"kernel": eng.last_beam_kernel(), "ms": round(dt * 1e3, 2), "users_per_s": round(U / dt)}
+eng.close()
+print(json.dumps(out))
