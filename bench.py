@@ -696,7 +696,7 @@ def main():
                      "gradient_exchange": ("dm_train_sync_gradients over dm_comm (%s)" % comm_transport) if comm is not None else "single worker"}
             if comm is not None:
                 st = eng.train_sync_stats()
-                train["exchange"] = {"rccl_nranks": st["nranks"], "transport": st["transport"], "ms_per_step": tr.sync_s / max(tr.sync_calls, 1) * 1e3,
+                train["exchange"] = {"rccl_nranks": st["nranks"] if st["transport"] == "rccl" else 0, "nranks": st["nranks"], "transport": st["transport"], "ms_per_step": tr.sync_s / max(tr.sync_calls, 1) * 1e3,
                                      "touched_rows_this_rank": st["rows_mine"], "touched_rows_all_ranks": st["rows_total"],
                                      "bytes_sent_per_step": st["bytes_sent"], "bytes_received_per_step": st["bytes_recv"],
                                      "host_syncs_per_step": st["host_syncs"], "rows_per_s_per_rank": Tt * per * nts / dtt}
