@@ -18,7 +18,7 @@ eng.load_weights_din_synthetic(E, NI, synth.SEED, tree_depth=depth, rho=0.95)
 out = {"users": U, "depth": depth, "beam": beam, "E": E}
 for L in (16, 17, 24, 32):
     seqs = synth.make_users(tree["leaf_ids"], U, L, np.random.default_rng(5))
-    eng.tdm_beam_search(seqs[:64], beam, beam)
+    eng.tdm_beam_search(seqs, beam, beam)                 # warm-up at full size: the workspace is allocated here
     t0 = time.perf_counter()
     ids, sc, cnt = eng.tdm_beam_search(seqs, beam, beam)
     dt = time.perf_counter() - t0
@@ -31,7 +31,7 @@ eng.load_weights_din_synthetic_f64(E, (1 << (d6 + 1)) - 1, synth.SEED)
 rng = np.random.default_rng(7)
 for L in (16, 24):
     codes = ((1 << d6) - 1 + rng.integers(0, 1 << d6, size=(U, L))).astype(np.int32)
-    eng.otm_beam_search_f64(codes[:64], beam, d6)
+    eng.otm_beam_search_f64(codes, beam, d6)
     t0 = time.perf_counter()
     eng.otm_beam_search_f64(codes, beam, d6)
     dt = time.perf_counter() - t0
