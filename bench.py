@@ -762,6 +762,17 @@ def main():
                                                      "frac": st_bytes / (st_ms * 1e-3) / 1e9 / 34500.0, "kernel_ms": st_ms, "bytes_per_user": st_bytes / Ud,
                                                      "note": "factor rows read through the eight XCD L2s (aggregate L2 peak, MI355X_MICROARCH.md); the tables' "
                                                              "column slices are L2-resident by construction (88 % TCC hits, profiles/r04_dr_*)"}
+            # the three lower bounds of one search step beside the measured time: the history GEMM at the matrix pipe's
+            # peak, the table / factor rows at the measured ~9.5 TB/s gather ceiling (tools/gather_microbench.hip), the exps at one per
+            # lane and ~25 (f32) / ~60 (f64) VALU instructions each over 1024 SIMDs x 16 lanes/clk
+            n_exp = float(sum(2 * Kd for _ in range(1, Dd)) + Kd + 2 * beam_d * Dd) * Ud
+            rl["bounds_ms_per_step"] = {"history_gemm_at_mfma_peak": gemm_flops / (peak_mm * 1e12) * 1e3,
+                                        "factor_rows_at_9.5_TBps": st_bytes / 9.5e12 * 1e3,
+                                        "exps": n_exp * (60 if tag == "f64" else 25) / (1024 * 16 * 2.4e9) * 1e3,
+                                        "measured_kernels": kms_b / nsd,
+                                        "note": "the sliced search evaluates ~2 K exps per user and layer (history factors) + the winners' exact probabilities "
+                                                "instead of one per candidate (beam x K per layer): the exp bound of the one-kernel search was ~%.2f ms"
+                                                % (float(sum(beam_d * Kd for _ in range(1, Dd)) + Kd) * Ud * (60 if tag == "f64" else 25) / (1024 * 16 * 2.4e9) * 1e3)}
             paths_h = np.empty((Ud, beam_d, Dd), np.int32)
             eng.d2h(paths_h, q_paths)
             eng.dr_recommend_dev(q_seq, Ud, beam_d, topk_d, q_ids, q_sc, q_cnt)
