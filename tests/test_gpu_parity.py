@@ -512,6 +512,46 @@ def test_train_step_vs_oracle_f64(oracle, fixture_w64, E, NI, B):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,E,L", [("f32", 128, 24), ("f32", 32, 32), ("f64", 128, 17), ("f64", 64, 32)])
+def test_train_step_long_histories(oracle, dtype, E, L):
+    """Histories of 17 .. 32 positions (the reference's Attention takes any length, scalann/.../nn/Attention.scala:34-53): the
+    training kernel's second instantiation (history loops unrolled to 32).  Same contract as the steps above: loss and every
+    gradient against the oracle's backward (fp32: 1e-5 / 1e-4, fp64: 1e-10 / 1e-9), Adam bit-exact on the device's gradient."""
+    from dismember_amd import Engine
+    f64 = dtype == "f64"
+    NI, B = 511, 333
+    rng = np.random.default_rng(E + L)
+    w = random_din_weights(rng, E, NI, std=0.2, bias_std=0.2, dtype=np.float64 if f64 else np.float32)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    eng.train_init(lr=1e-3)
+    codes, seqs, pad, y = _train_batch(rng, NI, B, L=L)
+    seqs[1, :] = seqs[1, 0] if seqs[1, 0] >= 0 else 5            # one key repeated L times
+    pad = np.flatnonzero(seqs.reshape(-1) == -1).astype(np.int32)
+    loss = eng.train_forward_backward(codes, seqs, pad, y)
+    g = eng.train_download("grad")
+    odin = oracle.Din(w.copy(), E, L, NI)
+    oloss, og = odin.train_grads(codes, seqs, pad, y)
+    if f64:
+        assert abs(loss - oloss) <= 1e-10 + 1e-9 * abs(oloss), (loss, oloss)
+        tol = 1e-10 * np.abs(og).max() + 1e-9 * np.abs(og)
+    else:
+        assert abs(loss - oloss) <= 1e-5 + 1e-4 * abs(oloss)
+        tol = 2e-5 * np.abs(og).max() + 1e-4 * np.abs(og)
+    assert (np.abs(g - og) <= tol).all(), float(np.abs(g - og).max())
+    eng.adam_step(1.0)
+    w1 = eng.train_download("weights")
+    ref = w.copy()
+    opt = oracle.Adam(ref.size, w.dtype.type, lr=1e-3)
+    opt.step(ref, g.copy())
+    assert np.array_equal(w1, ref)
+    loss2 = eng.train_forward_backward(codes, seqs, pad, y)
+    assert loss2 < loss
+    with pytest.raises(Exception):
+        eng.train_forward_backward(codes, np.zeros((B, 33), np.int32), None, y)
+    eng.close()
+
+
 def test_training_reduces_loss(fixture_w32):
     """scalann's own training tests assert a decreasing loss (SampledSoftmaxLossTest.scala:42-53); same here."""
     from dismember_amd import Engine
@@ -687,6 +727,49 @@ def test_otm_targets_on_device_ragged_batch(fixture_w64, fixture_otm_mapping, or
         for lv in range(len(nt) - 1, -1, -1):
             assert list(nt[lv][u].keys()) == anc and all(v == 1.0 for v in nt[lv][u].values())
             anc = list(dict.fromkeys((a - 1) >> 1 for a in anc))
+    eng.close()
+
+
+def test_otm_train_batch_long_history(oracle):
+    """The OTM iteration with 20 history positions (fp64): beam nodes from the per-level pipeline, pseudo targets, and the training
+    kernel's 32-position instantiation — node lists and labels equal to the fp64 oracle's, per-level losses at 1e-10."""
+    from dismember_amd import Engine
+    from dismember_amd.otm_train import OTMTrainer
+    from oracle import otm_oracle as oo
+    E, L, leaf_level, beam, U = 32, 20, 8, 12, 6
+    NI = (1 << (leaf_level + 1)) - 1
+    rng = np.random.default_rng(2024)
+    w = random_din_weights(rng, E, NI, std=0.2, bias_std=0.1, dtype=np.float64)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    tr = OTMTrainer(eng, leaf_level=leaf_level, beam=beam, seq_len=L, lr=1e-3)
+    first = (1 << leaf_level) - 1
+    codes = (first + rng.integers(0, 1 << leaf_level, (U, L))).astype(np.int32)
+    codes[rng.random((U, L)) < 0.3] = -1
+    targets = [(first + rng.choice(1 << leaf_level, int(rng.integers(1, 4)), replace=False)).tolist() for _ in range(U)]
+    odin = oracle.Din(w.copy(), E, L, NI)
+    got = tr.beam_search_nodes(codes)
+    assert "pipeline" in eng.last_beam_kernel()
+    ref = oo.beam_search_nodes(odin, codes, L, tr.start_level, leaf_level, beam)
+    for lv in range(len(ref)):
+        for u in range(U):
+            assert [n for n, _ in got[lv][u]] == [n for n, _ in ref[lv][u]], (lv, u)
+    tg = tr.optimal_pseudo_targets(targets, codes)
+    own = oo.optimal_pseudo_targets(odin, targets, codes, L, tr.start_level, leaf_level)
+    for lv in range(len(own)):
+        for u in range(U):
+            assert tg[lv][u].keys() == own[lv][u].keys() and all(abs(tg[lv][u][k] - own[lv][u][k]) < 1e-9 for k in tg[lv][u]), (lv, u)
+    losses = tr.train_batch(codes, targets)
+    opt = oracle.Adam(w.size, np.float64, lr=1e-3)
+    ref_losses = []
+    for lv in range(len(tg)):
+        c, s_, pad, y = oo.level_batch(got[lv], tg[lv], codes, L)
+        din = oracle.Din(w, E, L, NI)
+        loss, g = din.train_grads(c, s_, pad, y)
+        opt.step(w, g)
+        ref_losses.append(loss)
+    assert np.abs(np.array(losses) - np.array(ref_losses)).max() < 1e-10
+    assert np.abs(eng.train_download("weights") - w).max() < 1e-9
     eng.close()
 
 
