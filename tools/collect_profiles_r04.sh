@@ -7,6 +7,7 @@
 #   (3) the same with --scorer f32                                                                   -> prof_r04_f32
 #   (4) kernel trace + PMC passes of the fp64 OTM beam kernel at depth 24 (tools/otm_f64_bench.py)   -> prof_r04_otm64_d24
 #   (5) kernel trace + PMC passes of the Deep-Retrieval search, fp64 and f32 (tools/dr_bench.py)     -> prof_r04_dr_f64 / prof_r04_dr_f32
+#   (6) `otmtrain` (not part of `all`): the fp64 OTM training iteration at 8 192 users                 -> prof_r04_otmtrain
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WHAT=${1:-all}
@@ -32,4 +33,5 @@ if [ "$WHAT" = all ] || [ "$WHAT" = dr ]; then
   pmc_set gpurun_out/prof_r04_dr_f64 python tools/dr_bench.py --dtype f64 --rerank 0 --steps 4
   pmc_set gpurun_out/prof_r04_dr_f32 python tools/dr_bench.py --dtype f32 --rerank 0 --steps 4
 fi
+if [ "$WHAT" = otmtrain ]; then pmc_set gpurun_out/prof_r04_otmtrain python tools/otm_train_bench.py 24 8192 f64; fi     # fp64 OTM training iteration at train_batch_size 8192
 ls gpurun_out/prof_r04*/ | head -40

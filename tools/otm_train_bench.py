@@ -8,7 +8,10 @@ depth, E, L, beam = (int(sys.argv[1]) if len(sys.argv) > 1 else 24), 128, 10, 20
 U = int(sys.argv[2]) if len(sys.argv) > 2 else 20          # 20 users x 400 candidates = 8000 rows per level
 eng = Engine(0)
 ni = (1 << (depth + 1)) - 1
-eng.load_weights_din_synthetic(E, ni, synth.SEED, tree_depth=depth, rho=0.95)
+if len(sys.argv) > 3 and sys.argv[3] == "f64":          # the reference's DIN[Double]
+    eng.load_weights_din_synthetic_f64(E, ni, synth.SEED)
+else:
+    eng.load_weights_din_synthetic(E, ni, synth.SEED, tree_depth=depth, rho=0.95)
 rng = np.random.default_rng(3)
 first = (1 << depth) - 1
 seqs = (first + rng.integers(0, 1 << depth, size=(U, L))).astype(np.int32)
@@ -19,3 +22,4 @@ print("train_init (grad + Adam state for %d parameters): %.2f s" % (ni * E, time
 tr.train_batch(seqs, targets)
 t0 = time.perf_counter(); losses = tr.train_batch(seqs, targets); eng.synchronize(); dt = time.perf_counter() - t0
 print("OTM train_batch: %d users, %d levels (one Adam step each): %.2f s; losses %.4f .. %.4f" % (U, len(losses), dt, losses[0], losses[-1]))
+print(tr.last_stats())
