@@ -102,6 +102,8 @@ SIGNATURES = {
                                                 C.POINTER(SampleOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i64p]),
     "dm_train_forward_backward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                 f32p]),
+    "dm_train_forward_backward_grouped_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                        C.c_int, f32p]),
     "dm_dr_load_model": (C.c_int, [C.c_void_p, C.POINTER(DrModel)]),
     "dm_dr_load_path_items": (C.c_int, [C.c_void_p, i32p, C.c_int64, i64p, i32p]),
     "dm_dr_beam_search": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, i32p, C.POINTER(C.c_double), i32p]),

@@ -34,6 +34,7 @@
 #include "beam_kernel_f64.hip.inc"
 #include "rows_kernel.hip.inc"
 #include "train_kernel.hip.inc"
+#include "train_grouped_f64.hip.inc"
 #include "dr_kernel.hip.inc"
 #include "dr_sliced.hip.inc"
 
@@ -1790,6 +1791,7 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
 #include "tdm_pipeline.hip.inc"
 #include "comm.hip.inc"
 #include "jtm_sharded.hip.inc"
+#include "train_grouped_host.hip.inc"
 #include "otm_train.hip.inc"
 #include "checkpoint.hip.inc"
 #include "tree_file.hip.inc"

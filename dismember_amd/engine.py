@@ -367,6 +367,35 @@ class Engine:
         self._chk(N.lib().dm_train_forward_backward_dev(self._h, d_codes, d_seqs, d_mask, d_lab, n.value, L, C.byref(loss)))
         return loss.value
 
+    def train_forward_backward_grouped(self, seq_codes, user_mask, codes, labels):
+        """One forward/backward over a user-grouped batch (dm_train_forward_backward_grouped_dev): seq_codes [U][L], user_mask [U]
+        (bit j: position j masked) or None, codes / labels [U][n] — every user's n candidate rows share the user's history, as
+        MiniBatch.batchTransform / transformWithMask build them.  Returns the mean BCE loss (model precision)."""
+        seq = _i32(seq_codes)
+        U, L = seq.shape
+        codes = _i32(codes).reshape(U, -1)
+        n = codes.shape[1]
+        lab = np.ascontiguousarray(labels, np.float32).reshape(U, n)
+        al = lambda v: (v + 255) & ~255
+        need = al(U * L * 4) + al(U * 4) + 2 * al(U * n * 4)
+        buf = self.dev_alloc(need)
+        try:
+            base = buf.value
+            d_seq = C.c_void_p(base); base += al(U * L * 4)
+            d_um = C.c_void_p(base); base += al(U * 4)
+            d_codes = C.c_void_p(base); base += al(U * n * 4)
+            d_lab = C.c_void_p(base)
+            self.h2d(d_seq, seq); self.h2d(d_codes, codes); self.h2d(d_lab, lab)
+            if user_mask is not None:
+                self.h2d(d_um, np.ascontiguousarray(user_mask, np.uint32).ravel())
+            loss = C.c_float(0)
+            self._chk(N.lib().dm_train_forward_backward_grouped_dev(self._h, d_seq, d_um if user_mask is not None else None, d_codes, d_lab,
+                                                                    U, n, L, C.byref(loss)))
+            self.synchronize()
+        finally:
+            self.dev_free(buf)
+        return self.train_last_loss() if self.dtype == np.float64 else loss.value
+
     @staticmethod
     def rowmask_to_flat(mask, L):
         """Row bit masks -> the flat index list Module.forward takes (Mask.scala:27-32)."""

@@ -386,6 +386,14 @@ int dm_tdm_sample_train_batch_dev(dm_handle_t h, const int32_t *d_seq_item_ids, 
  * point validates them like LookupTable.scala:29-53): every code / history entry must be -1 or in [0, num_index). */
 int dm_train_forward_backward_dev(dm_handle_t h, const int32_t *d_codes, const int32_t *d_seqs, const uint32_t *d_rowmask,
                                   const float *d_labels, int64_t B, int L, float *loss);
+/* The same step for a batch in which every user contributes `rows_per_user` candidate rows that share the user's history — what
+ * MiniBatch.batchTransform (otm/.../dataset/MiniBatch.scala:17-40) and MiniBatch.transformWithMask (tdm/.../dataset/MiniBatch.scala:
+ * 129-147) build by replicating the history per row: d_seq_codes [U][L] (-1 = padding), d_user_mask [U] (bit j: position j masked;
+ * NULL = nothing masked), d_codes / d_labels [U * rows_per_user] user-major (code -1 = a zero item row).  Same loss and gradients as
+ * dm_train_forward_backward_dev on the expanded rows (fp64 sums in a different order); an f64 model with L <= 16 takes the per-user
+ * kernels (train_grouped_f64.hip.inc), anything else is expanded to plain rows.  Ids are not range-checked. */
+int dm_train_forward_backward_grouped_dev(dm_handle_t h, const int32_t *d_seq_codes, const uint32_t *d_user_mask, const int32_t *d_codes,
+                                          const float *d_labels, int64_t U, int rows_per_user, int L, float *loss);
 int dm_memcpy_d2d(dm_handle_t h, void *dst, const void *src, size_t bytes);
 
 /* ---- device-resident variants (bench: inputs already in HBM when the clock starts) ---- */
