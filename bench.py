@@ -907,17 +907,43 @@ def main():
             bseq6 = oc6[:Ub6]
             btg6 = (first6 + orng.integers(0, 1 << depth6, size=(Ub6, label_num))).tolist()
             tr6.train_batch(bseq6, btg6)
-            sync(); barrier()
+            sync(); eng.timing_reset(); barrier()
             t0 = time.perf_counter()
             lossesb = tr6.train_batch(bseq6, btg6)
             sync(); barrier()
             dtb6 = max_over_ranks(time.perf_counter() - t0)
             ph = tr6.last_stats()
+            # the forward/backward's kernels, HIP events around every launch (train_grouped_host.hip.inc): the row kernel is priced on the
+            # fp64 MFMAs it ISSUES — per 16-row tile: scores E/4, W1a forward and backward (E/16)^2 x 4 each, dp E/4, the two
+            # products over the ceil(L/4) k-steps of the history (E/16) x ceil(L/4) each — x 2048 flops, against the 78.6 TFLOP/s fp64 matrix peak
+            kq6 = (L + 3) // 4
+            mf_tile = 2 * (E // 4) + 2 * (E // 16) ** 2 * 4 + 2 * (E // 16) * kq6
+            nlv, nprev = [], None
+            lvl0 = 0
+            while (2 << lvl0) <= a.beam:
+                lvl0 += 1
+            nprev = 1 << lvl0
+            for _ in range(len(lossesb)):
+                nb_ = nprev if not nlv else min(a.beam, nprev)
+                nlv.append(2 * nb_); nprev = 2 * nb_
+            tiles6 = sum(Ub6 * ((n_ + 15) // 16) for n_ in nlv)
+            kt = {k_: eng.timing_get_kind(k_) for k_ in (40, 41, 42, 43, 44)}
+            roof_tr = None
+            if kt[41][0] == len(lossesb) and kt[41][1] > 0:
+                tf_ = tiles6 * mf_tile * 2048.0 / (kt[41][1] * 1e-3) / 1e12
+                mf_wg = tiles6 * ((E // 16) ** 2 + 2 * (E // 16)) * 4            # dW1a + the per-user dG / dK sums, four rows per MFMA
+                roof_tr = {"kernel": "tg_rows_kernel<%d, %d>" % (E, kq6), "bound": "mfma", "dtype": "f64", "achieved": tf_, "peak": 78.6,
+                           "unit": "TFLOP/s", "frac": tf_ / 78.6, "launches": kt[41][0], "avg_ms": kt[41][1] / kt[41][0],
+                           "issued_mfma_per_16_row_tile": mf_tile, "tiles": tiles6,
+                           "traffic": None, "traffic_note": "PMC passes of the same iteration: profiles/r05_otmtrain_summary.json",
+                           "other_kernels_ms_per_level": {"tg_setup": kt[40][1] / max(kt[40][0], 1), "tg_wgrad": kt[42][1] / max(kt[42][0], 1),
+                                                          "tg_user_bwd": kt[43][1] / max(kt[43][0], 1), "dm_wgrad (per-user rows)": kt[44][1] / max(kt[44][0], 1)},
+                           "tg_wgrad_frac_of_fp64_peak": (mf_wg * 2048.0 / (kt[42][1] * 1e-3) / 78.6e12) if kt[42][1] else None}
             otm64["train_iteration_batch_8192"] = {
                 "workload": "the same iteration at model.train_batch_size = %d users per worker x %d targets: %d levels x %d candidate rows"
                             % (Ub6, label_num, len(lossesb), Ub6 * 2 * a.beam),
                 "seconds": dtb6, "users_per_s": world * Ub6 / dtb6, "rows_per_s": world * ph["rows_trained"] / dtb6, "levels": len(lossesb),
-                "loss_first_level": float(lossesb[0]), "loss_last_level": float(lossesb[-1]),
+                "loss_first_level": float(lossesb[0]), "loss_last_level": float(lossesb[-1]), "roofline": roof_tr,
                 "phases": ph, "host_side_s": max(0.0, dtb6 - sum(ph[k] for k in ("pseudo_targets_s", "beam_search_s", "forward_backward_s", "exchange_s", "adam_s"))),
                 "adam_rows_visited_last_step": eng.adam_last_step_rows()[0],
                 "gradient_exchange": eng.train_sync_stats() if comm6 is not None else "single worker"}

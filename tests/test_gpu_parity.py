@@ -820,3 +820,49 @@ def test_otm_train_batch_vs_oracle(fixture_w64, fixture_otm_mapping, oracle, dty
         assert np.abs(np.array(losses) - np.array(ref_losses)).max() < 2e-4
         assert np.abs(wg - w).max() < 5e-4        # 8 Adam steps of lr 1e-3; sign-like updates amplify rounding near zero gradients
     eng.close()
+
+
+def test_otm_train_batch_long_history_f32(oracle):
+    """The same iteration on an f32 model with 20 history positions (round-4 advisor finding: the trainer used to hand such batches to the
+    fused f32 search and to the 16-position rows kernel, which truncate the history): beam nodes from the per-level pipeline, pseudo
+    targets through the general forward, the training kernel's 32-position instantiation.  Scores of the returned beam nodes against
+    the oracle's forward on the FULL history, per-level losses against the oracle's replay of the device's own lists (f32 contract)."""
+    from dismember_amd import Engine
+    from dismember_amd.otm_train import OTMTrainer
+    from oracle import otm_oracle as oo
+    E, L, leaf_level, beam, U = 32, 20, 8, 12, 6
+    NI = (1 << (leaf_level + 1)) - 1
+    rng = np.random.default_rng(2025)
+    w = random_din_weights(rng, E, NI, std=0.2, bias_std=0.1)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    tr = OTMTrainer(eng, leaf_level=leaf_level, beam=beam, seq_len=L, lr=1e-3)
+    first = (1 << leaf_level) - 1
+    codes = (first + rng.integers(0, 1 << leaf_level, (U, L))).astype(np.int32)
+    codes[rng.random((U, L)) < 0.3] = -1
+    codes[:, -1] = first + 5                                # the LAST position matters: a 16-position kernel would never see it
+    targets = [(first + rng.choice(1 << leaf_level, int(rng.integers(1, 4)), replace=False)).tolist() for _ in range(U)]
+    odin = oracle.Din(w.copy(), E, L, NI)
+    got = tr.beam_search_nodes(codes)
+    assert "pipeline" in eng.last_beam_kernel()
+    for lv in range(len(got)):
+        for u in range(U):
+            nodes = np.array([n for n, _ in got[lv][u]], np.int32)
+            sc = np.array([s_ for _, s_ in got[lv][u]])
+            pad = np.flatnonzero(np.tile(codes[u], (nodes.size, 1)).reshape(-1) == -1).astype(np.int32)
+            ref = odin.forward(nodes, np.tile(codes[u], (nodes.size, 1)), pad)
+            assert (np.abs(sc - ref) <= 1e-5 + 1e-4 * np.abs(ref)).all(), (lv, u)
+    tg = tr.optimal_pseudo_targets(targets, codes)
+    own = oo.optimal_pseudo_targets(odin, targets, codes, L, tr.start_level, leaf_level)
+    same = sum(tg[lv][u].keys() == own[lv][u].keys() for lv in range(len(own)) for u in range(U))
+    assert same >= 0.9 * len(own) * U                       # (f32 near-ties may move a label between siblings)
+    losses = tr.train_batch(codes, targets)
+    opt = oracle.Adam(w.size, np.float32, lr=1e-3)
+    ref_losses = []
+    for lv in range(len(tg)):
+        c, s_, pad, y = oo.level_batch(got[lv], tg[lv], codes, L)
+        loss, g = oracle.Din(w, E, L, NI).train_grads(c, s_, pad, y)
+        opt.step(w, g)
+        ref_losses.append(loss)
+    assert np.abs(np.array(losses) - np.array(ref_losses)).max() < 2e-4, (losses, ref_losses)
+    eng.close()
