@@ -357,6 +357,14 @@ def test_full_size_properties_depth24(oracle):
         a = jt.rebalance(w_gpu[grp], old_node[grp], int(node), old_level, level, 1)
         b = oracle.jtm_rebalance(jt.items[grp], w_gpu[grp], old_node[grp], int(node), old_level, level, 1)
         assert np.array_equal(a, b)
+    # the 3 000-item sub-catalogue end to end: JTM.optimize through all twelve gap steps of the depth-24 tree on the device, against the
+    # same assignment logic fed with the ORACLE's child weights (jtm/.../optim/JTM.scala:22-73, TreeLearning.scala:137-174): a bijection
+    # onto leaf codes, and the same leaf for (nearly) every item (a near-tie in fp32 weights may move an item)
+    proj = jt.optimize(as_array=True)
+    assert np.unique(proj).size == nit and proj.min() >= (1 << depth) - 1 and proj.max() <= (1 << (depth + 1)) - 2
+    ref = jt.optimize(weight_fn=lambda node, ol, lv: oracle.jtm_child_weights(otree, odin, jt.items, jt.row_off, jt.row_ids, node, L, ol, lv),
+                      as_array=True)
+    assert (proj == ref).mean() >= 0.9, float((proj == ref).mean())
     eng.close()
 
 
@@ -410,6 +418,57 @@ def test_full_size_otm_fp64_depth24():
     idf, scf, _ = eng.otm_beam_search(codes[1:3], beam, depth)
     ref32 = eng.din_forward(idf[0], np.tile(codes[1], (2 * beam, 1)), pad, L=L)
     assert (np.abs(scf[0] - ref32) <= ATOL + RTOL * np.abs(ref32)).all()
+    eng.set_scorer_mode("auto")
+    # ---- the conf's own batch (configs/c3_otm_10m.conf: train_batch_size 8192 users x label_num 5 targets, beam 200; round-4 verdict,
+    # next #4b): 16 levels x 3.28 M candidate rows + the first level's 2.1 M through the user-grouped fp64 kernels
+    # (otm/src/test/scala/OtmModelTrainSpec.scala:43-79 trains and checks that training ran; here: every level's loss finite, the
+    # same batch trained again scores lower, the target lists well-formed)
+    Ub, label_num = 8192, 5
+    brng = np.random.default_rng(10)
+    bcodes = (first + brng.integers(0, 1 << depth, size=(Ub, L))).astype(np.int32)
+    bcodes[brng.random((Ub, L)) < 0.15] = -1
+    btargets = (first + brng.integers(0, 1 << depth, size=(Ub, label_num))).tolist()
+    otb = OTMTrainer(eng, depth, beam, seq_len=L, lr=1e-3)
+    levels = depth - otb.start_level
+    tgl = otb.optimal_pseudo_targets(btargets, bcodes)
+    assert len(tgl) == levels
+    for u in (0, 1, Ub // 2, Ub - 1):
+        assert tgl[-1][u] == {int(t_): 1.0 for t_ in btargets[u]}                       # leaf level: the targets, label 1 (OTMTree.scala:38)
+        for lv in range(levels - 1):
+            kids, pars = tgl[lv + 1][u], tgl[lv][u]
+            assert set(pars) == {(k - 1) >> 1 for k in kids} and all(0.0 <= v <= 1.0 for v in pars.values())
+    lb1 = otb.train_batch(bcodes, btargets)
+    st = otb.last_stats()
+    assert st["rows_trained"] == Ub * (2 * (1 << otb.start_level) + (levels - 1) * 2 * beam) and st["users"] == Ub
+    lb2 = otb.train_batch(bcodes, btargets)
+    assert len(lb1) == levels and np.isfinite(lb1).all() and np.isfinite(lb2).all() and sum(lb2) < sum(lb1)
+    # a 16-user batch against oracle/otm_oracle.py on the SAME 34 GB of weights (as trained so far): beam nodes and pseudo-target lists
+    # equal, labels and the first level's loss at the fp64 contract.  Needs a host copy of the table.
+    if _host_mem_available() < NI * E * 8 + (24 << 30):
+        eng.close()
+        pytest.skip("full-size properties passed; oracle sub-batch skipped: host has %.0f GB available" % (_host_mem_available() / 1e9))
+    from oracle import otm_oracle as oo
+    from oracle import pyoracle as po
+    wq = eng.download_weights()
+    odin = po.Din(wq, E, L, NI)
+    Us = 16
+    scodes, stargets = bcodes[:Us], btargets[:Us]
+    got = otb.beam_search_nodes(scodes)
+    refn = oo.beam_search_nodes(odin, scodes, L, otb.start_level, depth, beam)
+    for lv in range(len(refn)):
+        for u in range(Us):
+            assert [n_ for n_, _ in got[lv][u]] == [n_ for n_, _ in refn[lv][u]], (lv, u)
+    tgs = otb.optimal_pseudo_targets(stargets, scodes)
+    own = oo.optimal_pseudo_targets(odin, stargets, scodes, L, otb.start_level, depth)
+    for lv in range(len(own)):
+        for u in range(Us):
+            assert tgs[lv][u].keys() == own[lv][u].keys() and all(abs(tgs[lv][u][k] - own[lv][u][k]) < 1e-9 for k in tgs[lv][u]), (lv, u)
+    c0, s0, pad0, y0 = oo.level_batch(got[0], tgs[0], scodes, L)
+    x0 = odin.forward(c0, s0, pad0)
+    ref_loss0 = float(np.mean(np.maximum(x0, 0) - x0 * y0 + np.log1p(np.exp(-np.abs(x0)))))
+    ls = otb.train_batch(scodes, stargets)
+    assert abs(ls[0] - ref_loss0) <= 1e-10 + 1e-9 * abs(ref_loss0), (ls[0], ref_loss0)
+    del odin, wq
     eng.close()
 
 
