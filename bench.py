@@ -93,6 +93,7 @@ def parse():
                     help="arithmetic of the headline run (include/dismember_hip.h: dm_set_scorer_mode; auto = the library default)")
     ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=1024, help="users for recall@topk vs brute force (0 skip)")
+    ap.add_argument("--diverse", type=int, default=1, help="also time the headline search on beams that DIVERGE (attention path x1.7, embeddings x32) and on an iid (rho 0) table; 0 = skip")
     ap.add_argument("--host-buffer-steps", type=int, default=3, help="steps of the headline workload through the host-buffer entry point (0 = skip)")
     ap.add_argument("--jtm-full", type=int, default=1, help="also time the FULL JTM.optimize over the 10M-item catalogue (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--jtm-rows", type=int, default=4, help="training rows per item of the full JTM.optimize extra")
@@ -360,17 +361,20 @@ def main():
     # over PCIe inside the call) — reported beside `value`, never as `value`
     host_rate = None
     if a.host_buffer_steps > 0:
-        eng.tdm_beam_search(shard_seqs[0], a.beam, a.topk)
+        hout = (np.empty((U, a.topk), np.int32), np.empty((U, a.topk), np.float32), np.empty(U, np.int32))     # a serving loop's own result buffers
+        eng.tdm_beam_search(shard_seqs[0], a.beam, a.topk, out=hout)             # shard 0: the device-resident results downloaded above
+        same_as_dev = bool(np.array_equal(hout[0], ids) and np.array_equal(hout[2], cnt) and np.array_equal(hout[1], sc))
         sync(); barrier()
         t0 = time.perf_counter()
         for i in range(a.host_buffer_steps):
-            eng.tdm_beam_search(shard_seqs[i % NSH], a.beam, a.topk)
+            eng.tdm_beam_search(shard_seqs[i % NSH], a.beam, a.topk, out=hout)
         sync(); barrier()
         dth = max_over_ranks(time.perf_counter() - t0)
         host_rate = {"host_buffer_users_per_s": world * U * a.host_buffer_steps / dth, "steps": a.host_buffer_steps,
-                     "ms_per_step": dth / a.host_buffer_steps * 1e3,
+                     "ms_per_step": dth / a.host_buffer_steps * 1e3, "identical_to_device_resident_results": same_as_dev,
                      "what": "the same users through dm_tdm_beam_search (host numpy buffers in and out: %d B up and %d B down per user over PCIe, "
-                             "pageable memory, result arrays allocated per call)" % (4 * L, 8 * a.topk + 4)}
+                             "pageable memory; the request is cut into chunks of users whose downloads run under the kernels of the chunks "
+                             "behind them, DM_HOST_PIPELINE)" % (4 * L, 8 * a.topk + 4)}
 
     stage("extra the same search with the OTHER scorer arithmetic (same engine, s")
     # ---- extra: the same search with the OTHER scorer arithmetic (same engine, same users) ----
@@ -406,6 +410,64 @@ def main():
                  "max_abs_score_diff_on_identical_lists": float(dsc.max()) if dsc.size else None,
                  "max_abs_score": float(np.abs(sc).max())}
 
+    stage("extra the headline search on beams that diverge / on an iid table")
+    # ---- extra: the same search where the users' beams DIVERGE (round-4 verdict, next #2).  With the reference's init the history term of the
+    # logit is several times smaller than the node term: the beams of different users overlap almost completely (distinct candidate
+    # rows per level: 0.1-0.2 % of users x candidates) and 97 % of the gathers hit L2.  Scaling the attention path (att.W, W1b) by 1.7
+    # and the embeddings by 32 (a sharp softmax) is the strongest history dependence that still fits the split scorer's fp16 range for
+    # every user (tools/diverse_bench.py explores the neighbourhood; beyond it users fall back to the LDS-fed kernel's fp32 product);
+    # it makes the beams user-specific (5-45 % distinct rows on the lower levels, 300 x more distinct result items).  Beside it: the
+    # literal SURVEY §8d table (iid rows, rho 0) with the reference init.  Same tree, same users, device-resident request.
+    diverse = None
+    if a.diverse and (a.items, a.depth) == (10_000_000, 24) and mode != "f32":
+        def _variant(att_scale, emb_scale, rho_):
+            r_ = np.random.default_rng(int(synth.SEED))
+            small_ = np.zeros(3 * E * E + 2 * E + 1, np.float32)
+            small_[:3 * E * E] = r_.standard_normal(3 * E * E, dtype=np.float32) * 0.05
+            small_[3 * E * E + E:3 * E * E + 2 * E] = r_.standard_normal(E, dtype=np.float32) * 0.05
+            small_[:E * E] *= att_scale
+            small_[E * E:3 * E * E].reshape(E, 2 * E)[:, E:] *= att_scale
+            e_ = Engine(int(os.environ.get("DM_FORCE_DEVICE", local)))
+            try:
+                e_.load_tree(tree["codes"], tree["ids"], tree["is_leaf"], depth); e_.load_id_maps(tree["leaf_ids"], tree["leaf_codes"])
+                e_.load_weights_din_synthetic(E, num_index, synth.SEED, small=small_, tree_depth=depth, rho=rho_, std=0.05 * emb_scale)
+                e_.set_scorer_mode(a.scorer)
+                e_.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+                e_.synchronize(); e_.timing_reset(); barrier()
+                nst = max(3, a.steps // 3)
+                t0_ = time.perf_counter()
+                for i_ in range(nst):
+                    e_.tdm_beam_search_dev(d_seqs[i_ % NSH], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
+                e_.synchronize(); barrier()
+                dt_ = max_over_ranks(time.perf_counter() - t0_) / nst
+                n0_, k0_ = e_.timing_get_kind(0); n1_, k1_ = e_.timing_get_kind(1)
+                ids_ = np.empty((U, a.topk), np.int32); e_.d2h(ids_, d_ids)
+                Us_ = min(4096, U)
+                tr_ = e_.tdm_beam_search_trace(shard_seqs[(nst - 1) % NSH][:Us_], a.beam, a.topk)
+                tc_, tn_ = tr_[3], tr_[5]
+                frac_ = []
+                for lv_ in range(tn_.shape[1]):
+                    if tn_[:, lv_].max() > 0:
+                        cand_ = np.concatenate([tc_[u_, lv_, :tn_[u_, lv_]] for u_ in range(Us_)])
+                        frac_.append(round(float(np.unique(cand_).size) / float(cand_.size), 4))
+                return {"att_scale": att_scale, "emb_scale": emb_scale, "rho": rho_, "users_per_s": world * U / dt_, "ms_per_step": dt_ * 1e3,
+                        "kernel": e_.last_beam_kernel(), "kernel_ms": k0_ / max(n0_, 1), "deferred_users_pass_ms": k1_ / max(n1_, 1), "steps": nst,
+                        "distinct_result_items": int(np.unique(ids_[ids_ >= 0]).size),
+                        "distinct_candidate_rows_per_level_fraction_4096_users": frac_}
+            finally:
+                e_.close()
+        try:
+            div_ = _variant(1.7, 32.0, a.rho)
+            iid_ = _variant(1.0, 1.0, 0.0)
+            diverse = {"workload": "the headline search (same tree, users, beam, topk; device-resident request) on a model whose beams diverge, and on an iid table",
+                       "diverse_beams": div_, "iid_table_rho0": iid_,
+                       "headline_ms_per_step": dt / a.steps * 1e3,
+                       "diverse_slowdown_vs_headline": div_["ms_per_step"] / (dt / a.steps * 1e3),
+                       "iid_slowdown_vs_headline": iid_["ms_per_step"] / (dt / a.steps * 1e3),
+                       "pmc": "profiles/r05_diverse_summary.json (L2 hit rate 0.667, 129 GB fetched per launch) beside profiles/r05_diverse_head_summary.json (0.968, 11.4 GB)"}
+        except Exception as ex:       # noqa: BLE001 — an extra must not cost the headline line
+            diverse = {"skipped": repr(ex)}
+
     if rank == 0:
         avg_ms = kernel_ms / max(n_launch, 1)
         roof = roofline(mode, rows, avg_ms, E, L, kern_name)
@@ -429,6 +491,10 @@ def main():
             "roofline": roof,
             "scorer": {"mode": mode, "shift_emb": info["shift_emb"], "shift_w": info["shift_w"]},
         }
+        if diverse is not None:
+            res["extra_diverse_beams"] = diverse
+            if "diverse_beams" in diverse:
+                res["diverse_beams_users_per_s"] = diverse["diverse_beams"]["users_per_s"]
         if host_rate is not None:
             res["host_buffer"] = host_rate
             res["host_buffer_users_per_s"] = host_rate["host_buffer_users_per_s"]
@@ -438,7 +504,7 @@ def main():
         res["roofline"]["traffic"] = None
         res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         why = None
-        for tag in ("r04", "r03"):               # newest committed profile set first
+        for tag in ("r05", "r04", "r03"):        # newest committed profile set first
             pname = "%s_summary.json" % tag if mode != "f32" else "%s_f32_summary.json" % tag
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
@@ -516,8 +582,10 @@ def main():
             eng.otm_beam_search_dev(d_os, Uo, L, a.beam, depth, d_oi, d_osc, d_oc)
         sync(); barrier()
         dto = max_over_ranks(time.perf_counter() - t0)
+        oout = (np.empty((Uo, 2 * a.beam), np.int32), np.empty((Uo, 2 * a.beam), np.float32), np.empty(Uo, np.int32))
+        eng.otm_beam_search(ocodes, a.beam, depth, out=oout)             # (first touch of the result buffers)
         t0 = time.perf_counter()
-        oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth)      # host buffers: PCIe copies of 3.3 KB per user included
+        oid, osc, ocnt = eng.otm_beam_search(ocodes, a.beam, depth, out=oout)      # host buffers: PCIe copies of 3.3 KB per user included
         dth = time.perf_counter() - t0
         for d_ in (d_os, d_oi, d_osc, d_oc):
             eng.dev_free(d_)

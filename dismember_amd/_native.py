@@ -51,6 +51,7 @@ SIGNATURES = {
     "dm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dm_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "dm_destroy": (C.c_int, [C.c_void_p]),
+    "dm_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dm_last_error": (C.c_char_p, [C.c_void_p]),
     "dm_synchronize": (C.c_int, [C.c_void_p]),
     "dm_load_tree_tdm": (C.c_int, [C.c_void_p, i32p, i32p, u8p, C.c_int64, C.c_int]),

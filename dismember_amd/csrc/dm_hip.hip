@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <cerrno>
@@ -66,6 +67,13 @@ struct dm_ctx {
   int n_cu = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  // dm_clone: a clone reads the tree, the weights and every derived copy of its parent (same device memory) through its own stream,
+  // request arenas and workspace.  model_epoch counts the changes of anything a clone mirrors; mu serialises the lazy rebuilds.
+  dm_ctx *parent = nullptr;
+  std::atomic<int> n_clones{0};
+  std::atomic<uint64_t> model_epoch{1};
+  uint64_t seen_epoch = 0;
+  std::recursive_mutex mu;
   // tree (codeNodeMap as bitmaps + dense node-id array)
   bool tree_loaded = false, ids_loaded = false, leaves_at_max_only = true;
   int max_level = 0;
@@ -153,6 +161,10 @@ struct dm_ctx {
   char *h_stage = nullptr;     // pinned staging block for small host-buffer requests (one upload, one download per call)
   char *d_stage = nullptr;     // the same block as the kernels address it (hipHostGetDevicePointer): single-request path
   size_t stage_bytes = 0;
+  // pipelined host-buffer searches (host_pipe_*): a second, non-blocking stream for the result downloads + one event per chunk
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> chunk_ev;
+  bool rows_keep = false;      // a later chunk of one request: the scored-rows counter keeps counting
   // cached search workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -380,13 +392,22 @@ int dm_create(int device_id, dm_handle_t *out) {
   return DM_OK;
 }
 
+static inline void model_changed(dm_ctx *h) { h->model_epoch.fetch_add(1); }
+static int clone_enter(dm_ctx *c);
+// entry points that replace the model or train it: the owning handle only
+#define DM_OWNER_ONLY(h, who) do { if ((h)->parent) return fail((h), DM_ERR_STATE, who ": not on a clone (dm_clone) - load and train through the owning handle"); } while (0)
+// read-only entry points: a clone first brings its mirror of the parent's model up to date
+#define DM_CLONE_ENTER(h) do { if ((h)->parent) { const int rc_ce_ = clone_enter(h); if (rc_ce_ != DM_OK) return rc_ce_; } } while (0)
+
 static void free_tree(dm_ctx *h) {
+  model_changed(h);
   dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start);
   h->d_lv_codes = nullptr; h->d_lv_cdf = nullptr; h->d_lv_start = nullptr;
   dm_free_ptr(h->d_exists); dm_free_ptr(h->d_leaf); dm_free_ptr(h->d_node_id); dm_free_ptr(h->d_leaf_codes);
   h->d_exists = h->d_leaf = nullptr; h->d_node_id = h->d_leaf_codes = nullptr; h->tree_loaded = false;
 }
 static void free_weights(dm_ctx *h) {
+  model_changed(h);
   if (h->emb32_owned) dm_free_ptr(h->d_emb32);
   dm_free_ptr(h->d_compact); dm_free_ptr(h->d_wfrag); dm_free_ptr(h->d_afrag); dm_free_ptr(h->d_bfrag); dm_free_ptr(h->d_attA); dm_free_ptr(h->d_w1aA); dm_free_ptr(h->d_w1bA);
   dm_free_ptr(h->d_b1); dm_free_ptr(h->d_w2); dm_free_ptr(h->d_att_wT_t); dm_free_ptr(h->d_l1T_t);
@@ -404,16 +425,96 @@ static void free_weights(dm_ctx *h) {
   h->d_afrag = h->d_bfrag = nullptr; h->d_attA = h->d_w1aA = h->d_w1bA = nullptr; h->d_b1 = h->d_w2 = nullptr; h->d_att_wT_t = h->d_l1T_t = nullptr; h->w_loaded = false;
 }
 
+// Everything a clone mirrors from its parent: the tree, the id maps, the weights and every derived copy (fragment orders, split planes,
+// the pre-split table, the f32 mirror of an f64 model, the fp64 fragments).  One list drives the mirror and the clone's tear-down.
+#define DM_SHARED_FIELDS(X)                                                                                                              \
+  X(tree_loaded) X(ids_loaded) X(leaves_at_max_only) X(max_level) X(n_slots) X(n_leaf_nodes) X(d_exists) X(d_leaf) X(d_node_id)          \
+  X(d_id_to_code) X(d_leaf_codes) X(non_leaf_offset) X(max_code) X(w_loaded) X(dtype) X(embed) X(embed_log) X(num_index) X(d_compact)    \
+  X(d_emb32) X(d_wfrag) X(d_afrag) X(d_bfrag) X(d_attA) X(d_w1aA) X(d_w1bA) X(d_b1) X(d_w2) X(b2) X(d_wsplit) X(d_rows_split) X(sh_r)    \
+  X(d_emb_split) X(emb_split_bytes) X(d_maxabs) X(sh_e) X(sh_w) X(d_att_wT_t) X(d_l1T_t) X(d_frag64) X(b2_64) X(d_tail32)                \
+  X(d_lv_codes) X(d_lv_cdf) X(d_lv_start)
+
+static void clone_mirror(dm_ctx *c, dm_ctx *p) {
+#define X(f) c->f = p->f;
+  DM_SHARED_FIELDS(X)
+#undef X
+  c->h_id_to_code = p->h_id_to_code;
+  c->h_exists = p->h_exists;
+  c->emb32_owned = false;
+  // the parent's copies were brought up to date before the mirror was taken: nothing is stale for the clone, and nothing is rebuilt by it
+  c->split_dirty = false; c->emb_split_dirty = false; c->rows_split_dirty = false; c->frag64_dirty = false; c->f32_mirror_dirty = false;
+  c->table_dense_change = false; c->sh_e_valid = p->sh_e_valid; c->emb_split_need_full = false; c->emb_split_patch = false;
+  c->seen_epoch = p->model_epoch.load();
+}
+static void clone_forget(dm_ctx *c) {         // the clone owns none of it
+  dm_ctx z;
+#define X(f) c->f = z.f;
+  DM_SHARED_FIELDS(X)
+#undef X
+  c->emb32_owned = false;
+}
+
+static bool use_split(const dm_ctx *h);
+static bool use_f64_beam(const dm_ctx *h);
+static int ensure_split(dm_ctx *h);
+static int ensure_rows_split(dm_ctx *h);
+static int ensure_f32_mirror(dm_ctx *h);
+static int ensure_frags64(dm_ctx *h);
+
+// A clone's read-only entry points start here.  Fast path: the parent's model has not changed since the mirror was taken (one atomic
+// load).  Otherwise, under the parent's lock: the copies this clone's scorer needs are brought up to date ON THE PARENT (its stream,
+// its buffers; no-ops when clean), the parent's stream is drained, and the mirror is retaken.  Weight updates through the parent must
+// not overlap a clone's search in flight — the reference's workers wait for each other the same way (LocalOptimizer.scala:73-80).
+static int clone_enter(dm_ctx *c) {
+  dm_ctx *p = c->parent;
+  if (c->seen_epoch == p->model_epoch.load()) return DM_OK;
+  std::lock_guard<std::recursive_mutex> lock(p->mu);
+  if (hipSetDevice(p->device) != hipSuccess) return fail(c, DM_ERR_HIP, "dm_clone: hipSetDevice failed");
+  for (int pass = 0; pass < 2; pass++) {
+    clone_mirror(c, p);                         // (first pass: the model's shape, so that the scorer choice below is this clone's)
+    if (!p->w_loaded) break;
+    int rc = DM_OK;
+    if (use_f64_beam(c)) rc = ensure_frags64(p);        // (decided on the clone: the parent's model with the clone's own scorer setting)
+    else {
+      rc = ensure_f32_mirror(p);
+      if (rc == DM_OK && use_split(c)) { rc = ensure_split(p); if (rc == DM_OK) rc = ensure_rows_split(p); }
+    }
+    if (rc != DM_OK) { c->err = p->err; return rc; }
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return fail(c, DM_ERR_HIP, "dm_clone: the parent's stream failed");
+  }
+  return DM_OK;
+}
+
+int dm_clone(dm_handle_t h, dm_handle_t *out) {
+  if (!h || !out) return DM_ERR_INVALID;
+  *out = nullptr;
+  dm_ctx *root = h->parent ? h->parent : h;      // a clone of a clone shares the same owner
+  dm_handle_t c = nullptr;
+  int rc = dm_create(root->device, &c);
+  if (rc != DM_OK) return fail(h, rc, g_create_err);
+  c->parent = root;
+  c->scorer_mode = h->scorer_mode;
+  root->n_clones.fetch_add(1);
+  rc = clone_enter(c);
+  if (rc != DM_OK) { h->err = c->err; root->n_clones.fetch_sub(1); c->parent = nullptr; dm_destroy(c); return rc; }
+  *out = c;
+  return DM_OK;
+}
+
 int dm_destroy(dm_handle_t h) {
   if (!h) return DM_ERR_INVALID;
+  if (h->n_clones.load() > 0) return fail(h, DM_ERR_STATE, "dm_destroy: the handle still has clones (dm_clone): destroy them first");
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->parent) { clone_forget(h); h->parent->n_clones.fetch_sub(1); h->parent = nullptr; }
   free_tree(h); free_weights(h); dm_dr_free(h->dr);
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer); dm_free_ptr(h->d_scratch64);
   dm_free_ptr(h->d_jtm_off); dm_free_ptr(h->d_jtm_ritem); dm_free_ptr(h->d_jtm_rids);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto &e_ : h->chunk_ev) (void)hipEventDestroy(e_);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return DM_OK;
@@ -433,6 +534,7 @@ int dm_level_start(int candidate_num, int *start_code, int *level) {
 int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_ids, const uint8_t *is_leaf,
                      int64_t n_nodes, int max_level) {
   if (!h) return DM_ERR_INVALID;
+  DM_OWNER_ONLY(h, "dm_load_tree_tdm");
   if (!codes || !node_ids || !is_leaf || n_nodes <= 0 || max_level < 0 || max_level > 30)
     return fail(h, DM_ERR_INVALID, "dm_load_tree_tdm: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
@@ -472,6 +574,7 @@ int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_id
 
 int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *leaf_codes, int64_t n) {
   if (!h) return DM_ERR_INVALID;
+  DM_OWNER_ONLY(h, "dm_load_id_maps");
   if (!leaf_item_ids || !leaf_codes || n <= 0) return fail(h, DM_ERR_INVALID, "dm_load_id_maps: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   int32_t mid = -1, mcode = -1;
@@ -480,6 +583,7 @@ int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *
     if (leaf_codes[i] > mcode) mcode = leaf_codes[i];
   }
   if (mid < 0) return fail(h, DM_ERR_INVALID, "dm_load_id_maps: no non-negative item id");
+  model_changed(h);
   h->non_leaf_offset = mid + 1;   // DistTree.scala:35
   h->max_code = mcode;            // DistTree.scala:36
   h->h_id_to_code.assign((size_t)h->non_leaf_offset, -1);
@@ -494,6 +598,7 @@ int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *
 
 int dm_tdm_id_to_code(dm_handle_t h, const int32_t *item_ids, int n, int32_t *codes, int32_t *mask_pos, int *n_mask) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (!h->ids_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_id_to_code: id maps not loaded");
   if (!item_ids || !codes || !mask_pos || !n_mask || n < 0) return fail(h, DM_ERR_INVALID, "dm_tdm_id_to_code: bad arguments");
   int nm = 0;
@@ -647,6 +752,7 @@ static int load_weights_any_t(dm_ctx *h, int E, int64_t num_index, const T *w, i
 
 int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, const void *compact, int64_t n_elems) {
   if (!h) return DM_ERR_INVALID;
+  DM_OWNER_ONLY(h, "dm_load_weights_din");
   if (!compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: bad arguments");
   if (E < 1 || E > 128)
     return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 1 .. 128 (sizes other than 16 / 32 / 64 / 128 are zero-padded to the next of them)");
@@ -659,6 +765,7 @@ int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, cons
 
 int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_compact, int64_t n_elems) {
   if (!h) return DM_ERR_INVALID;
+  DM_OWNER_ONLY(h, "dm_load_weights_din_dev");
   if (!d_compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev: bad arguments");
   if (E != 16 && E != 32 && E != 64 && E != 128) return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din_dev: embed size must be 16, 32, 64 or 128");
   const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
@@ -680,6 +787,7 @@ int dm_load_weights_din_dev(dm_handle_t h, int E, int64_t num_index, float *d_co
 // throughput-mode beam kernels read is made here
 int dm_load_weights_din_dev_f64(dm_handle_t h, int E, int64_t num_index, double *d_compact, int64_t n_elems) {
   if (!h) return DM_ERR_INVALID;
+  DM_OWNER_ONLY(h, "dm_load_weights_din_dev_f64");
   if (!d_compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din_dev_f64: bad arguments");
   if (E != 16 && E != 32 && E != 64 && E != 128) return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din_dev_f64: embed size must be 16, 32, 64 or 128");
   const int64_t need = num_index * E + (int64_t)E * E + (int64_t)E * 2 * E + E + E + 1;
@@ -818,6 +926,7 @@ static int split_shift(unsigned maxbits);
 static bool weights_in_motion(const dm_ctx *h);
 // fp16 planes of the general-rows split kernel (rows_kernel.hip.inc): follow the weights like the beam kernels' planes
 static int ensure_rows_split(dm_ctx *h) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   int rc = ensure_split_scales(h);     // sh_e = the table's scale: one read of the table per weight change, shared with the beam kernels
   if (rc != DM_OK) return rc;
   if (!h->rows_split_dirty && h->d_rows_split) return DM_OK;
@@ -831,6 +940,7 @@ static int ensure_rows_split(dm_ctx *h) {
   unsigned mb[2];
   HIPCHK(h, hipMemcpyAsync(mb, h->d_maxabs, 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  model_changed(h);
   h->sh_r = split_shift(mb[0] > mb[1] ? mb[0] : mb[1]);
   hipLaunchKernelGGL(dm_build_rows_planes_kernel, dim3(64), dim3(256), 0, h->stream, h->d_w1aA, (const float *)Mbuf, E, ldexpf(1.0f, h->sh_r),
                      (_Float16 *)h->d_rows_split);
@@ -887,6 +997,7 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
 int dm_din_forward(dm_handle_t h, const int32_t *codes, const int32_t *seqs, const int32_t *pad_flat_idx,
                    int64_t n_pad, int64_t B, int L, void *logits) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (!h->w_loaded) return fail(h, DM_ERR_STATE, "dm_din_forward: weights not loaded");
   if (!codes || !seqs || !logits || B < 0 || L <= 0 || L > 32 || n_pad < 0 || (n_pad > 0 && !pad_flat_idx))
     return fail(h, DM_ERR_INVALID, "dm_din_forward: bad arguments (L must be 1..32)");
@@ -1169,7 +1280,9 @@ static int split_shift(unsigned maxbits) {
 // scales (2^sh_e from max|emb|: one read of the table; 2^sh_w from max|W1a|) and the fp16 planes of W1a: what every split kernel
 // needs.  The pre-split copy of the table (ensure_split) is a second, larger step only the beam kernels take.
 static int ensure_split_scales(dm_ctx *h) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   if (!h->split_dirty && h->d_wsplit) return DM_OK;
+  model_changed(h);
   const int E = h->embed;
   if (E % 32 != 0) return fail(h, DM_ERR_UNSUPPORTED, "the split-fp16 scorer needs an embedding size that is a multiple of 32");
   if (!h->d_wsplit) ALLOC(h, h->d_wsplit, (size_t)E * E * 4);
@@ -1208,9 +1321,11 @@ static int ensure_split_scales(dm_ctx *h) {
 }
 
 static int ensure_split(dm_ctx *h) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   int rc = ensure_split_scales(h);
   if (rc != DM_OK) return rc;
   if (!h->emb_split_dirty && h->d_emb_split) return DM_OK;
+  model_changed(h);
   const int E = h->embed;
   // the beam kernels gather pre-split rows: a second copy of the table (same size), refreshed whenever the weights change — as a whole,
   // or in the active rows only when nothing else can have moved
@@ -1329,6 +1444,7 @@ int dm_set_scorer_mode(dm_handle_t h, int mode) {
   if (mode == DM_SCORER_SPLIT_F16 && h->w_loaded && h->embed % 32 != 0)
     return fail(h, DM_ERR_UNSUPPORTED, "dm_set_scorer_mode: the split-fp16 scorer needs an embedding size of 32, 64 or 128");
   h->scorer_mode = mode;
+  if (h->parent) h->seen_epoch = 0;      // a clone: its next call makes sure the parent holds the copies this setting reads
   return DM_OK;
 }
 
@@ -1407,11 +1523,47 @@ static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, con
       return rc_;
     }
   }
-  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
+  if (h->rows_keep) HIPCHK(h, hipMemsetAsync(h->d_rows + 1, 0, 8, h->stream));      // (the work-queue head only)
+  else HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
   HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
   return launch_beam(h, p, pl);
+}
+
+// ---- pipelined host-buffer searches.  The reference-shaped entry points take and return host arrays; at serving batch sizes the results
+// are the bulk of a call (131 072 users x 200 x 8 B = 210 MB) and used to come down AFTER the kernel, through pageable memory: 98.6 ms per
+// call against 77.5 ms for the kernel alone (round-4 bench).  Large requests are now cut into chunks of users: every chunk's kernel is
+// enqueued up front on the handle's stream with an event behind it, and the host thread downloads chunk k on a second, non-blocking
+// stream as soon as its event fires — under the kernels of the chunks behind it.  Only the last chunk's download is exposed.
+// DM_HOST_PIPELINE=0 keeps the one-launch path (A/B).
+// Chunk k covers users [off[k], off[k + 1]): equal chunks of about 24 MB of results, then a SHORT last one (its download is the only
+// one nothing hides; 8 192 users still fill the persistent grid eight users deep).  n = 1: the request is not cut.
+static int host_pipe_plan(size_t bytes_per_user, int64_t U, int64_t *off /* [18] */) {
+  static const bool disabled = [] { const char *e = getenv("DM_HOST_PIPELINE"); return e && e[0] == '0'; }();
+  off[0] = 0; off[1] = U;
+  const size_t out_bytes = bytes_per_user * (size_t)U;
+  if (disabled || U < 16384 || out_bytes < (32u << 20)) return 1;
+  const int64_t last = U >= 65536 ? 8192 : 4096;
+  const int64_t rest = U - last;
+  int n = (int)((bytes_per_user * (size_t)rest + (24u << 20) - 1) / (24u << 20));
+  if (n > 16) n = 16;
+  if ((int64_t)n > rest / 4096) n = (int)(rest / 4096);
+  if (n < 1) n = 1;
+  const int64_t Uc = (((rest + n - 1) / n) + 255) / 256 * 256;
+  int k = 0;
+  for (; k < n && (int64_t)k * Uc < rest; k++) off[k] = (int64_t)k * Uc;
+  off[k] = rest; off[k + 1] = U;
+  return k + 1;
+}
+static int host_pipe_ensure(dm_ctx *h, int n) {
+  if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  while ((int)h->chunk_ev.size() < n) {
+    hipEvent_t e;
+    HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->chunk_ev.push_back(e);
+  }
+  return DM_OK;
 }
 
 static int host_max_beam(const dm_tdm_search_opts *o, const int64_t *coff, int64_t U) {
@@ -1428,6 +1580,8 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
                            const int64_t *d_consumed_off, const int32_t *d_consumed_ids, int32_t *d_out_item_ids,
                            float *d_out_scores, int32_t *d_out_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
+  DM_CLONE_ENTER(h);
   if (!d_seq_item_ids || !opts || !d_out_item_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
   int mb = opts->beam;
@@ -1511,6 +1665,34 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
       // the plan did not allow it (one-wave-per-SIMD kernel, too many users for the grid): fall through to the staged path
     }
     if (hipMemcpyAsync(d_seq, staged ? (const void *)h->h_stage : (const void *)seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
+    int64_t coff_[18];
+    const int n_chunks = (staged || coff || tn || L > DM_MAXL) ? 1 : host_pipe_plan((size_t)opts->topk * 8, U, coff_);
+    if (n_chunks > 1) {
+      if ((rc = host_pipe_ensure(h, n_chunks)) != DM_OK) break;
+      int launched = 0;
+      for (int k = 0; k < n_chunks && rc == DM_OK; k++) {
+        const int64_t u0 = coff_[k], uk = coff_[k + 1] - u0;
+        if (uk <= 0) break;
+        h->rows_keep = k > 0;
+        rc = tdm_search_dev(h, d_seq + u0 * L, uk, L, opts, mb, nullptr, nullptr, d_ids + u0 * opts->topk, d_scores + u0 * opts->topk, d_counts + u0,
+                            0, nullptr, nullptr, nullptr);
+        h->rows_keep = false;
+        if (rc == DM_OK && hipEventRecord(h->chunk_ev[(size_t)k], h->stream) != hipSuccess) rc = fail(h, DM_ERR_HIP, "tdm beam search: event record failed");
+        if (rc == DM_OK) launched++;
+      }
+      hipError_t e = hipSuccess;
+      for (int k = 0; k < launched && e == hipSuccess; k++) {
+        const int64_t u0 = coff_[k], uk = coff_[k + 1] - u0;
+        e = hipStreamWaitEvent(h->copy_stream, h->chunk_ev[(size_t)k], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_ids + u0 * opts->topk, d_ids + u0 * opts->topk, (size_t)uk * opts->topk * 4, hipMemcpyDeviceToHost, h->copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_scores + u0 * opts->topk, d_scores + u0 * opts->topk, (size_t)uk * opts->topk * 4, hipMemcpyDeviceToHost, h->copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_counts + u0, d_counts + u0, (size_t)uk * 4, hipMemcpyDeviceToHost, h->copy_stream);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+      const hipError_t e2 = hipStreamSynchronize(h->stream);
+      if (rc == DM_OK && (e != hipSuccess || e2 != hipSuccess)) rc = fail(h, DM_ERR_HIP, std::string("tdm beam search (pipelined download): ") + hipGetErrorString(e != hipSuccess ? e : e2));
+      break;
+    }
     if (coff) {
       d_coff = (int64_t *)base; base += b_coff;
       d_cids = (int32_t *)base; base += b_cids;
@@ -1557,6 +1739,7 @@ int dm_tdm_beam_search(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, in
                        const int64_t *consumed_off, const int32_t *consumed_ids, int32_t *out_item_ids, float *out_scores,
                        int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   return tdm_search_host(h, seq_item_ids, U, L, opts, consumed_off, consumed_ids, out_item_ids, out_scores, out_counts, 0,
                          nullptr, nullptr, nullptr);
 }
@@ -1565,6 +1748,7 @@ int dm_tdm_beam_search_trace(dm_handle_t h, const int32_t *seq_item_ids, int64_t
                              int32_t *out_item_ids, float *out_scores, int32_t *out_counts, int max_levels,
                              int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search_trace: bad trace arguments");
   return tdm_search_host(h, seq_item_ids, U, L, opts, nullptr, nullptr, out_item_ids, out_scores, out_counts, max_levels,
                          trace_codes, trace_scores, trace_counts);
@@ -1587,7 +1771,8 @@ static int otm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, int
   HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * stride * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * stride * 4, h->stream));
   HIPCHK(h, hipMemsetAsync(d_counts, 0, (size_t)U * 4, h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
+  if (h->rows_keep) HIPCHK(h, hipMemsetAsync(h->d_rows + 1, 0, 8, h->stream));
+  else HIPCHK(h, hipMemsetAsync(h->d_rows, 0, 16, h->stream));
   BeamParams p;
   fill_common(h, p);
   const size_t per = (size_t)pl.grid * pl.nteams * pl.ws_cap;
@@ -1612,6 +1797,7 @@ static int otm_check(dm_ctx *h, int64_t U, int L, int beam, int leaf_level, cons
 int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U, int L, int beam, int leaf_level,
                            int32_t *d_out_node_ids, float *d_out_scores, int32_t *d_out_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   int rc = otm_check(h, U, L, beam, leaf_level, "dm_otm_beam_search_dev");
   if (rc != DM_OK) return rc;
   if (U == 0) return DM_OK;
@@ -1660,6 +1846,38 @@ static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L
   int32_t *d_tc = tn ? (int32_t *)(base + o_tc) : nullptr, *d_tn = tn ? (int32_t *)(base + o_tn) : nullptr;
   float *d_ts = tn ? (float *)(base + o_ts) : nullptr;
   HIPCHK(h, hipMemcpyAsync(d_seq, seq_codes, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream));
+  int64_t coff_[18];
+  const int n_chunks = tn ? 1 : host_pipe_plan(stride * 8, U, coff_);
+  if (n_chunks > 1) {      // chunks of users, downloads under the kernels behind them (host_pipe_plan)
+    if ((rc = host_pipe_ensure(h, n_chunks)) != DM_OK) return rc;
+    int launched = 0;
+    for (int k = 0; k < n_chunks && rc == DM_OK; k++) {
+      const int64_t u0 = coff_[k], uk = coff_[k + 1] - u0;
+      if (uk <= 0) break;
+      SearchPlan plk;
+      if ((rc = plan_search(h, beam, uk, L, leaf_level - level, false, &plk)) != DM_OK) break;
+      h->rows_keep = k > 0;
+      rc = otm_search_dev(h, d_seq + u0 * L, uk, L, beam, leaf_level, d_ids + u0 * stride, d_scores + u0 * stride, d_counts + u0, 0, nullptr, nullptr, nullptr, plk);
+      h->rows_keep = false;
+      if (rc == DM_OK && hipEventRecord(h->chunk_ev[(size_t)k], h->stream) != hipSuccess) rc = fail(h, DM_ERR_HIP, "dm_otm_beam_search: event record failed");
+      if (rc == DM_OK) launched++;
+    }
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < launched && e == hipSuccess; k++) {
+      const int64_t u0 = coff_[k], uk = coff_[k + 1] - u0;
+      e = hipStreamWaitEvent(h->copy_stream, h->chunk_ev[(size_t)k], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(out_node_ids + u0 * stride, d_ids + u0 * stride, (size_t)uk * stride * 4, hipMemcpyDeviceToHost, h->copy_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(out_scores + u0 * stride, d_scores + u0 * stride, (size_t)uk * stride * 4, hipMemcpyDeviceToHost, h->copy_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(out_counts + u0, d_counts + u0, (size_t)uk * 4, hipMemcpyDeviceToHost, h->copy_stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+    if (rc != DM_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->stream); return fail(h, DM_ERR_HIP, std::string("dm_otm_beam_search (pipelined download): ") + hipGetErrorString(e)); }
+    HIPCHK(h, hipMemcpyAsync(&h->h_rows, h->d_rows, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->last_rows = (int64_t)h->h_rows;
+    return DM_OK;
+  }
   if (tn) HIPCHK(h, hipMemsetAsync(d_tn, 0, nt * 4, h->stream));
   if ((rc = otm_search_dev(h, d_seq, U, L, beam, leaf_level, d_ids, d_scores, d_counts, max_levels, d_tc, d_ts, d_tn, pl)) != DM_OK) return rc;
   if (tn) {
@@ -1679,6 +1897,7 @@ static int otm_search_host(dm_ctx *h, const int32_t *seq_codes, int64_t U, int L
 int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L, int beam, int leaf_level,
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (use_f64_beam(h) || L > DM_MAXL)      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, 0, nullptr, nullptr, nullptr, nullptr);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, 0, nullptr, nullptr, nullptr);
@@ -1688,6 +1907,7 @@ int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U,
                              int32_t *out_node_ids, float *out_scores, int32_t *out_counts, int max_levels,
                              int32_t *trace_codes, float *trace_scores, int32_t *trace_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_trace: bad trace arguments");
   if (use_f64_beam(h) || L > DM_MAXL)
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, max_levels, trace_codes,
@@ -1702,6 +1922,7 @@ int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U,
 int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, int topk, int use_mask,
                            int32_t *out_item_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
+  DM_CLONE_ENTER(h);
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_bruteforce_topk: tree, id maps and weights must be loaded first");
   if (U == 0 && L > 0 && L <= DM_MAXL && topk > 0 && topk <= 256) return DM_OK;          // an empty batch is not an error
   if (!seq_item_ids || !out_item_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || topk <= 0 || topk > 256)

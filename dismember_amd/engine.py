@@ -30,9 +30,22 @@ class Engine:
         self.E = None
         self.dtype = None
 
+    def clone(self):
+        """dm_clone: a second engine on the same device that reads this engine's tree, weights and derived copies (no copy is made)
+        through its own stream and request buffers — the reference's cloneModule() workers (LocalOptimizer.scala:28-44).  Loading and
+        training go through the owner; close the clones first."""
+        c = Engine.__new__(Engine)
+        c._h = C.c_void_p()
+        self._chk(N.lib().dm_clone(self._h, C.byref(c._h)))
+        c.E, c.dtype = self.E, self.dtype
+        c._owner = self                      # keeps the owner alive for as long as the clone exists
+        return c
+
     def close(self):
         if getattr(self, "_h", None):
-            N.lib().dm_destroy(self._h)
+            rc = N.lib().dm_destroy(self._h)
+            if rc != 0:
+                raise DismemberError(rc, (N.lib().dm_last_error(self._h) or b"").decode())
             self._h = None
 
     def __del__(self):
@@ -77,16 +90,16 @@ class Engine:
         self._chk(N.lib().dm_load_weights_din(self._h, dt, int(E), int(num_index), w.ctypes.data_as(C.c_void_p), w.size))
         self.E, self.dtype, self.num_index = int(E), w.dtype, int(num_index)
 
-    def load_weights_din_synthetic(self, E, num_index, seed, small=None, tree_depth=None, rho=0.0):
+    def load_weights_din_synthetic(self, E, num_index, seed, small=None, tree_depth=None, rho=0.0, std=0.05):
         """Build the compact DIN vector on the device (N(0, 0.05) table; `small` = host array holding
         [att.W ; l1.W ; l1.b ; l2.W ; l2.b], defaults to the reference init) and load it without a host copy."""
         n = num_index * E + 3 * E * E + 2 * E + 1
         d = self.dev_alloc(n * 4)
         if tree_depth is not None and rho > 0.0:
             assert num_index == (1 << (tree_depth + 1)) - 1
-            self._chk(N.lib().dm_fill_tree_normal(self._h, d, int(E), int(tree_depth), float(rho), 0.05, int(seed)))
+            self._chk(N.lib().dm_fill_tree_normal(self._h, d, int(E), int(tree_depth), float(rho), float(std), int(seed)))
         else:
-            self._chk(N.lib().dm_fill_normal(self._h, d, num_index * E, 0.0, 0.05, int(seed)))
+            self._chk(N.lib().dm_fill_normal(self._h, d, num_index * E, 0.0, float(std), int(seed)))
         if small is None:
             rng = np.random.default_rng(int(seed))
             small = np.zeros(3 * E * E + 2 * E + 1, np.float32)
@@ -177,16 +190,23 @@ class Engine:
         ids = _i32(np.concatenate([_i32(c) for c in consumed]) if off[U] > 0 else np.zeros(1, np.int32))
         return off, ids
 
-    def tdm_beam_search(self, seq_item_ids, beam, topk, use_mask=True, consumed=None, widen_consumed=False):
+    def tdm_beam_search(self, seq_item_ids, beam, topk, use_mask=True, consumed=None, widen_consumed=False, out=None):
+        """out: optional (ids [U, topk] int32, scores [U, topk] float32, counts [U] int32) to fill — a serving loop reuses its result
+        buffers (fresh 200 MB arrays page-fault on every call, inside the download)."""
         seq = _i32(seq_item_ids)
         if seq.ndim == 1:
             seq = seq[None, :]
         U, L = seq.shape
         opts = N.SearchOpts(int(beam), int(topk), int(bool(use_mask)), int(bool(widen_consumed)))
         off, cids = self._csr(consumed, U)
-        ids = np.empty((U, topk), np.int32)
-        sc = np.empty((U, topk), np.float32)
-        cnt = np.empty(U, np.int32)
+        if out is not None:
+            ids, sc, cnt = out
+            assert ids.shape == (U, topk) and ids.dtype == np.int32 and sc.shape == (U, topk) and sc.dtype == np.float32
+            assert cnt.shape == (U,) and cnt.dtype == np.int32 and ids.flags.c_contiguous and sc.flags.c_contiguous
+        else:
+            ids = np.empty((U, topk), np.int32)
+            sc = np.empty((U, topk), np.float32)
+            cnt = np.empty(U, np.int32)
         self._chk(N.lib().dm_tdm_beam_search(self._h, _p(seq, N.i32p), U, L, C.byref(opts),
                                              None if off is None else _p(off, N.i64p),
                                              None if cids is None else _p(cids, N.i32p), _p(ids, N.i32p),
@@ -213,14 +233,19 @@ class Engine:
                                                    _p(ts, N.f32p), _p(tn, N.i32p)))
         return ids, sc, cnt, tc, ts, tn
 
-    def otm_beam_search(self, seq_codes, beam, leaf_level):
+    def otm_beam_search(self, seq_codes, beam, leaf_level, out=None):
         seq = _i32(seq_codes)
         if seq.ndim == 1:
             seq = seq[None, :]
         U, L = seq.shape
-        ids = np.empty((U, 2 * beam), np.int32)
-        sc = np.empty((U, 2 * beam), np.float32)
-        cnt = np.empty(U, np.int32)
+        if out is not None:
+            ids, sc, cnt = out
+            assert ids.shape == (U, 2 * beam) and ids.dtype == np.int32 and sc.shape == (U, 2 * beam) and sc.dtype == np.float32
+            assert cnt.shape == (U,) and cnt.dtype == np.int32 and ids.flags.c_contiguous and sc.flags.c_contiguous
+        else:
+            ids = np.empty((U, 2 * beam), np.int32)
+            sc = np.empty((U, 2 * beam), np.float32)
+            cnt = np.empty(U, np.int32)
         self._chk(N.lib().dm_otm_beam_search(self._h, _p(seq, N.i32p), U, L, int(beam), int(leaf_level), _p(ids, N.i32p),
                                              _p(sc, N.f32p), _p(cnt, N.i32p)))
         return ids, sc, cnt

@@ -53,6 +53,16 @@ int dm_version(void);
 int dm_device_count(int *count);
 int dm_create(int device_id, dm_handle_t *out);
 int dm_destroy(dm_handle_t h);
+/* A second handle on the same device that READS the tree, the id maps, the weights and every derived copy (fragment orders, split
+ * planes, the pre-split table) of `h` — the same device memory, nothing is copied — through its own stream, request arenas and
+ * workspace: the reference's `cloneModule()` workers share one weight storage (tdm/.../optim/LocalOptimizer.scala:28-44, pinned by
+ * otm/src/test/scala/CloneModelSpec.scala:20-36).  One host thread per handle, as everywhere; searches through `h` and its clones run
+ * concurrently.  Loading and training go through the owning handle only (DM_ERR_STATE on a clone); a clone sees the new weights at its
+ * next call.  Weight updates must not overlap a clone's search in flight (the reference's workers meet at a barrier before the update,
+ * LocalOptimizer.scala:73-80).  Destroy the clones before the owner (dm_destroy(owner) fails with DM_ERR_STATE while clones exist).
+ * A clone of a clone shares the same owner.  The Deep-Retrieval model is per handle (not shared). */
+int dm_clone(dm_handle_t h, dm_handle_t *clone);
+
 const char *dm_last_error(dm_handle_t h); /* h may be NULL: last create-time error */
 int dm_synchronize(dm_handle_t h);        /* hipStreamSynchronize on the handle's stream */
 

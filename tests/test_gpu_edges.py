@@ -888,3 +888,141 @@ def test_tree_file_loaded_by_the_library_and_tdm_predict(tmp_path, fixture_tree,
         assert e.value.code == -1, name
         assert all(np.array_equal(x, y) for x, y in zip(rb, b.tdm_beam_search(users, 20, 10))), name      # the old index is intact
     a.close(); b.close()
+
+
+def _free_device_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    f, t_ = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(f), C.byref(t_)) == 0
+    return f.value
+
+
+def test_clone_shares_weights_and_serves_concurrently(oracle):
+    """dm_clone ("weights shareable read-only across handles of one device"; the reference's cloneModule() workers share
+    one weight storage, tdm/.../optim/LocalOptimizer.scala:28-44, otm/src/test/scala/CloneModelSpec.scala:20-36 "cloned model shares
+    weights, and a change through one is visible through the other").  A clone allocates no second table, returns what the owner
+    returns — also while both search at once from two host threads — sees a training step made through the owner, refuses to load or
+    train, and must be destroyed before the owner."""
+    import threading
+    from dismember_amd import Engine, DismemberError
+    rng = np.random.default_rng(77)
+    E, depth, n_items, L, beam, topk = 128, 16, 3000, 10, 64, 50          # a 67 MB table: a copied table would show
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    w = random_din_weights(rng, E, NI)
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(w, E, NI)
+    seqs = random_histories(rng, t["leaf_ids"], 4096, L)
+    ref = eng.tdm_beam_search(seqs, beam, topk)
+    free0 = _free_device_bytes()
+    c1, c2 = eng.clone(), eng.clone()
+    assert free0 - _free_device_bytes() < NI * E * 4 // 2         # two clones together (streams, counters) cost less than HALF a table: nothing was copied
+    for c in (c1, c2):
+        got = c.tdm_beam_search(seqs, beam, topk)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+        assert c.scorer_mode()["mode"] == eng.scorer_mode()["mode"]
+    # concurrently: three host threads, three handles, one table
+    outs, errs = {}, []
+    def run(name, e_, lo, hi):
+        try:
+            for _ in range(3):
+                outs[name] = e_.tdm_beam_search(seqs[lo:hi], beam, topk)
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    ths = [threading.Thread(target=run, args=(n_, e_, lo, hi)) for n_, e_, lo, hi in (("o", eng, 0, 4096), ("a", c1, 0, 2048), ("b", c2, 2048, 4096))]
+    [th.start() for th in ths]; [th.join() for th in ths]
+    assert not errs, errs
+    assert all(np.array_equal(a, b) for a, b in zip(outs["o"], ref))
+    assert all(np.array_equal(a[:2048], b) for a, b in zip(ref, outs["a"])) and all(np.array_equal(a[2048:], b) for a, b in zip(ref, outs["b"]))
+    # the other read-only entry points and the other scorer through a clone
+    c1.set_scorer_mode("f32"); eng.set_scorer_mode("f32")
+    assert all(np.array_equal(a, b) for a, b in zip(eng.tdm_beam_search(seqs[:256], beam, topk), c1.tdm_beam_search(seqs[:256], beam, topk)))
+    eng.set_scorer_mode("auto"); c1.set_scorer_mode("auto")
+    codes = rng.integers(0, NI, 300).astype(np.int32); hs = rng.integers(0, NI, (300, L)).astype(np.int32)
+    assert np.array_equal(eng.din_forward(codes, hs, None), c2.din_forward(codes, hs, None))
+    assert np.array_equal(eng.id_to_code(seqs[0])[0], c2.id_to_code(seqs[0])[0])
+    # training through the owner is visible through the clones (their next call re-mirrors the refreshed copies)
+    eng.train_init(lr=1e-2)
+    y = (rng.random(300) < 0.3).astype(np.float32)
+    eng.train_forward_backward(codes, hs, None, y); eng.adam_step(1.0)
+    after = eng.tdm_beam_search(seqs[:512], beam, topk)
+    assert not all(np.array_equal(a[:512], b) for a, b in zip(ref, after))          # the step moved the scores
+    for c in (c1, c2):
+        got = c.tdm_beam_search(seqs[:512], beam, topk)
+        assert all(np.array_equal(a, b) for a, b in zip(after, got))
+    assert np.array_equal(eng.din_forward(codes, hs, None), c1.din_forward(codes, hs, None))
+    # a clone neither loads nor trains; the owner outlives its clones
+    with pytest.raises(DismemberError):
+        c1.load_weights_din(w, E, NI)
+    with pytest.raises(DismemberError):
+        c1.train_init(lr=1e-3)
+    with pytest.raises(DismemberError):
+        eng.close()
+    c3 = c1.clone()                                                # a clone of a clone shares the same owner
+    assert all(np.array_equal(a, b) for a, b in zip(after, c3.tdm_beam_search(seqs[:512], beam, topk)))
+    c3.close(); c1.close(); c2.close()
+    eng.close()
+
+
+def test_clone_of_an_f64_model_serves_the_fp64_search(oracle):
+    """The same for a DIN[Double] (OTM): the clone reads the owner's fp64 table and fragments; node lists and scores identical."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(78)
+    E, leaf_level, beam = 32, 9, 24
+    NI = (1 << (leaf_level + 1)) - 1
+    w = random_din_weights(rng, E, NI, dtype=np.float64, std=0.2, bias_std=0.1)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    codes = rng.integers((1 << leaf_level) - 1, NI, (64, 10)).astype(np.int32)
+    codes[rng.random(codes.shape) < 0.2] = -1
+    c = eng.clone()
+    a = eng.otm_beam_search_f64(codes, beam, leaf_level)
+    b = c.otm_beam_search_f64(codes, beam, leaf_level)
+    assert all(np.array_equal(x, y_) for x, y_ in zip(a, b))
+    din = oracle.Din(w, E, 10, NI)
+    oi, osc = oracle.otm_beam_search(din, codes[3], leaf_level, beam)
+    assert np.array_equal(b[0][3, :b[2][3]], oi)
+    c.close(); eng.close()
+
+
+def test_host_buffer_searches_pipeline_their_downloads_and_equal_the_device_resident_path():
+    """Large host-buffer requests (dm_tdm_beam_search / dm_otm_beam_search) are cut into chunks of users whose result downloads run
+    under the kernels of the chunks behind them (host_pipe_chunks, dm_hip.hip).  Same ids, scores and counts as ONE launch over the
+    device-resident request (dm_*_beam_search_dev), for a user count that does not divide into the chunks; the scored-rows counter
+    covers the whole request."""
+    from dismember_amd import Engine
+    rng = np.random.default_rng(91)
+    E, depth, n_items, L, beam, topk = 32, 11, 2000, 10, 100, 200
+    t = synthetic_tree(rng, depth, n_items)
+    NI = (1 << (depth + 1)) - 1
+    eng = Engine(0)
+    eng.load_tree(t["codes"], t["ids"], t["is_leaf"], int(t["max_level"])); eng.load_id_maps(t["leaf_ids"], t["leaf_codes"])
+    eng.load_weights_din(random_din_weights(rng, E, NI), E, NI)
+    U = 50_001                                                     # 80 MB of results: three chunks, the last one ragged
+    seqs = random_histories(rng, t["leaf_ids"], U, L)
+    d_seq, d_ids, d_sc, d_cnt = eng.dev_alloc(U * L * 4), eng.dev_alloc(U * topk * 4), eng.dev_alloc(U * topk * 4), eng.dev_alloc(U * 4)
+    eng.h2d(d_seq, seqs)
+    eng.tdm_beam_search_dev(d_seq, U, L, beam, topk, d_ids, d_sc, d_cnt)
+    eng.synchronize()
+    rows_dev = eng.last_scored_rows()
+    ids, sc, cnt = np.empty((U, topk), np.int32), np.empty((U, topk), np.float32), np.empty(U, np.int32)
+    eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
+    out = (np.full((U, topk), -7, np.int32), np.full((U, topk), -7, np.float32), np.full(U, -7, np.int32))
+    eng.tdm_beam_search(seqs, beam, topk, out=out)
+    assert np.array_equal(out[0], ids) and np.array_equal(out[1], sc) and np.array_equal(out[2], cnt)
+    assert eng.last_scored_rows() == rows_dev
+    # OTM mode, same table
+    first = (1 << depth) - 1
+    codes = (first + rng.integers(0, 1 << depth, (U, L))).astype(np.int32)
+    codes[rng.random((U, L)) < 0.2] = -1
+    eng.h2d(d_seq, codes)
+    eng.otm_beam_search_dev(d_seq, U, L, beam, depth, d_ids, d_sc, d_cnt)
+    eng.synchronize()
+    eng.d2h(ids, d_ids); eng.d2h(sc, d_sc); eng.d2h(cnt, d_cnt)
+    o2 = eng.otm_beam_search(codes, beam, depth)
+    assert np.array_equal(o2[0], ids) and np.array_equal(o2[1], sc) and np.array_equal(o2[2], cnt)
+    for d_ in (d_seq, d_ids, d_sc, d_cnt):
+        eng.dev_free(d_)
+    eng.close()

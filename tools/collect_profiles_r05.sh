@@ -35,4 +35,8 @@ if [ "$WHAT" = all ] || [ "$WHAT" = dr ]; then
 fi
 if [ "$WHAT" = jtm ]; then pmc_set gpurun_out/prof_r05_jtm python tools/jtm_bench.py 10000000 24; fi     # JTM.optimize at 10 M items: the general-rows split kernel
 if [ "$WHAT" = otmtrain ]; then pmc_set gpurun_out/prof_r05_otmtrain python tools/otm_train_bench.py 24 8192 f64; fi     # fp64 OTM training iteration at train_batch_size 8192
+if [ "$WHAT" = diverse ]; then       # the headline search on beams that diverge (tools/diverse_bench.py) beside the shared-beam headline model
+  pmc_set gpurun_out/prof_r05_diverse python tools/diverse_bench.py 131072 4 s1.7e32
+  pmc_set gpurun_out/prof_r05_diverse_head python tools/diverse_bench.py 131072 4 head
+fi
 ls gpurun_out/prof_r05*/ | head -40
