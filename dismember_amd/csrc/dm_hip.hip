@@ -73,6 +73,7 @@ struct dm_ctx {
   std::atomic<int> n_clones{0};
   std::atomic<uint64_t> model_epoch{1};
   uint64_t seen_epoch = 0;
+  uint64_t ids_epoch = 1;      // generation of the id maps (dm_load_id_maps)
   std::recursive_mutex mu;
   // tree (codeNodeMap as bitmaps + dense node-id array)
   bool tree_loaded = false, ids_loaded = false, leaves_at_max_only = true;
@@ -180,6 +181,9 @@ struct dm_ctx {
   // JTM: the catalogue's training rows kept on the device across gap steps (dm_jtm_cache_rows)
   int64_t *d_jtm_off = nullptr;
   int32_t *d_jtm_ritem = nullptr, *d_jtm_rids = nullptr;
+  int32_t *d_jtm_rseq = nullptr;       // the rows' history CODES [rows][L] and pad masks [rows] (built once per cached catalogue and id map:
+  unsigned *d_jtm_rmask = nullptr;     //  they do not change between the gap steps unless the ancestors are taken per level — hierarchical mode)
+  uint64_t jtm_rseq_ids_epoch = 0;     // id-map generation the codes were built from
   std::vector<int64_t> jtm_off;
   int jtm_L = 0;
   struct dm_comm *comm = nullptr;
@@ -511,7 +515,7 @@ int dm_destroy(dm_handle_t h) {
   dm_free_ptr(h->d_id_to_code); dm_free_ptr(h->d_rows); dm_free_ptr(h->d_phase); dm_free_ptr(h->d_ws); dm_free_ptr(h->d_req); dm_free_ptr(h->d_sync);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   dm_free_ptr(h->d_lv_codes); dm_free_ptr(h->d_lv_cdf); dm_free_ptr(h->d_lv_start); dm_free_ptr(h->d_samp); dm_free_ptr(h->d_defer); dm_free_ptr(h->d_scratch64);
-  dm_free_ptr(h->d_jtm_off); dm_free_ptr(h->d_jtm_ritem); dm_free_ptr(h->d_jtm_rids);
+  dm_free_ptr(h->d_jtm_off); dm_free_ptr(h->d_jtm_ritem); dm_free_ptr(h->d_jtm_rids); dm_free_ptr(h->d_jtm_rseq); dm_free_ptr(h->d_jtm_rmask);
   for (auto &pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto &e_ : h->chunk_ev) (void)hipEventDestroy(e_);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -584,6 +588,7 @@ int dm_load_id_maps(dm_handle_t h, const int32_t *leaf_item_ids, const int32_t *
   }
   if (mid < 0) return fail(h, DM_ERR_INVALID, "dm_load_id_maps: no non-negative item id");
   model_changed(h);
+  h->ids_epoch++;
   h->non_leaf_offset = mid + 1;   // DistTree.scala:35
   h->max_code = mcode;            // DistTree.scala:36
   h->h_id_to_code.assign((size_t)h->non_leaf_offset, -1);
@@ -964,7 +969,7 @@ static int launch_rows_split_E(dm_ctx *h, const RowsSplitParams &p) {
 
 // f32 general-rows forward on device buffers (asynchronous on the handle's stream)
 static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
-                        int L, float *d_out) {
+                        int L, float *d_out, int seq_div = 1) {
   // the default arithmetic for E = 32 / 64 / 128 (DM_SCORER_F32 keeps the fp32-input kernel below).  While a training loop keeps
   // moving the weights (AUTO mode) a batch below ~4 M rows is cheaper on the fp32-input kernel than the table scan for the new scale.
   if (use_split(h) && !(weights_in_motion(h) && B < ((int64_t)1 << 22))) {
@@ -974,7 +979,7 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
     q.emb = h->d_emb32; q.planes = (const dm_h8 *)h->d_rows_split; q.b1 = h->d_b1; q.w2 = h->d_w2; q.b2 = h->b2;
     q.emb_scale = ldexpf(1.0f, h->sh_e); q.out_unscale = ldexpf(1.0f, -(h->sh_e + h->sh_r));
     q.num_index = h->num_index; q.codes = d_codes; q.seqs = d_seqs; q.rowmask = d_rowmask; q.B = B; q.L = L; q.out = d_out;
-    q.sm_scale = sm_scale32(h);
+    q.sm_scale = sm_scale32(h); q.seq_div = seq_div;
     switch (h->embed) {
       DM_IF_ALL_E(case 32: return launch_rows_split_E<32>(h, q);)
       DM_IF_ALL_E(case 64: return launch_rows_split_E<64>(h, q);)
@@ -984,7 +989,7 @@ static int din_rows_dev(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs
   RowsParams p;
   p.emb = h->d_emb32; p.attA = h->d_attA; p.w1aA = h->d_w1aA; p.w1bA = h->d_w1bA; p.b1 = h->d_b1; p.w2 = h->d_w2;
   p.b2 = h->b2; p.num_index = h->num_index; p.codes = d_codes; p.seqs = d_seqs; p.rowmask = d_rowmask; p.B = B; p.L = L;
-  p.out = d_out; p.sm_scale = sm_scale32(h);
+  p.out = d_out; p.sm_scale = sm_scale32(h); p.seq_div = seq_div;
   switch (h->embed) {
     DM_IF_ALL_E(case 16: return launch_rows_E<16>(h, p);)
     DM_IF_ALL_E(case 32: return launch_rows_E<32>(h, p);)

@@ -23,6 +23,7 @@
 #include <map>
 #include <thread>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -81,12 +82,23 @@ struct Error : std::runtime_error {
 
 // one dm_handle_t = one device + stream; not copyable
 class Engine {
+  explicit Engine(dm_handle_t adopted) : h_(adopted) {}      // cloneEngine()
  public:
   explicit Engine(int device_id = 0) {
     const int rc = dm_create(device_id, &h_);
     if (rc != DM_OK) throw Error(rc, dm_last_error(nullptr) ? dm_last_error(nullptr) : "");
   }
   ~Engine() { if (h_) dm_destroy(h_); }
+  // Module.cloneModule() as the reference's workers use it (tdm/.../optim/LocalOptimizer.scala:28-44; otm/src/test/scala/
+  // CloneModelSpec.scala:20-36): a second engine that READS this engine's tree and weights (dm_clone: nothing is copied) through its
+  // own stream and buffers — one per serving thread.  Loading and training stay with the owner; destroy the clones first.
+  std::unique_ptr<Engine> cloneEngine() const {
+    dm_handle_t c = nullptr;
+    check(dm_clone(h_, &c));
+    std::unique_ptr<Engine> e(new Engine(c));
+    e->maxLevel_ = maxLevel_; e->embed_ = embed_;
+    return e;
+  }
   Engine(const Engine &) = delete;
   Engine &operator=(const Engine &) = delete;
   dm_handle_t handle() const { return h_; }

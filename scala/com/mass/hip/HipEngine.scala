@@ -5,12 +5,23 @@ package com.mass.hip
 
 /** Property.readConf / getOrStop (scalann/src/main/scala/com/mass/scalann/utils/Property.scala:12-71) are unchanged in the
   * reference and keep reading configs/*.conf; this engine only replaces what the tasks do with the values. */
-final class HipEngine(val device: Int = 0) extends AutoCloseable {
-  private val out = new Array[Long](1)
-  Native.create(device, out)
-  val handle: Long = out(0)
+final class HipEngine private (val device: Int, adopted: Long) extends AutoCloseable {
+  def this(device: Int = 0) = this(device, 0L)
+  val handle: Long = if (adopted != 0L) adopted else { val out = new Array[Long](1); Native.create(device, out); out(0) }
   private var embed = 0
   private var maxLevel_ = 0
+
+  /** Module.cloneModule() as the reference's worker threads use it (tdm/.../optim/LocalOptimizer.scala:28-44, pinned by
+    * otm/src/test/scala/CloneModelSpec.scala:20-36): an engine that READS this engine's tree and weights — the same device memory,
+    * dm_clone copies nothing — through its own stream and request buffers, one per serving thread.  Loading and training stay with
+    * the owner; close the clones first. */
+  def cloneEngine(): HipEngine = {
+    val out = new Array[Long](1)
+    Native.clone(handle, out)
+    val c = new HipEngine(device, out(0))
+    c.embed = embed; c.maxLevel_ = maxLevel_
+    c
+  }
 
   def maxLevel: Int = maxLevel_
   def embedSize: Int = embed

@@ -40,6 +40,11 @@ int main(int argc, char **argv) {
     dm::TDM tdm(eng, "DIN");
     std::printf("{\n");
     printRecs("tdm_recommend", tdm.recommend(query, topk, beam));
+    {   // cloneModule(): a worker's engine reads the owner's model (dm_clone) and recommends the same
+      auto worker = eng.cloneEngine();
+      dm::TDM tdm2(*worker, "DIN");
+      printRecs("tdm_recommend_clone", tdm2.recommend(query, topk, beam));
+    }
     {
       const auto a = tdm.recommendItems(query, topk, beam);
       const auto b = tdm.recommendItems(query, topk, beam, &consumed);

@@ -70,6 +70,7 @@ def test_cpp_facade_matches_python_mirror_and_oracle(tmp_path, fixture_tree, fix
     tdm = TDM(eng, "din")
     py = tdm.recommend(query, topk, beam)
     assert [r[0] for r in out["tdm_recommend"]] == [r[0] for r in py]
+    assert out["tdm_recommend_clone"] == out["tdm_recommend"]            # dm::Engine::cloneEngine(): the worker's engine reads the owner's model
     assert np.allclose([r[1] for r in out["tdm_recommend"]], [r[1] for r in py], rtol=0, atol=1e-15)    # libm vs numpy exp: 1 ulp
     assert out["items_plain"] == tdm.recommend_items(query, topk, beam).tolist()
     assert out["items_consumed"] == tdm.recommend_items(query, topk, beam, consumed_items=consumed).tolist()
