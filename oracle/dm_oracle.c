@@ -13,6 +13,10 @@
  *   - structural invariants restated in tests/test_oracle.py
  *   - the reference's bundled trained weights / tree (tests/golden/ .npy and .npz files)
  *     as golden INPUTS; outputs on them are restatement-derived.
+ *   - what the bundled TRAINED weights separate when read through this restatement (round 5,
+ *     tests/test_oracle.py::test_trained_weights_pin_layout, tools/trained_weights_pin_probe.py): the concat order
+ *     [item; att] of linear1's input, the positions of l1.b / l2.W / l2.b in the compact vector and the sign of l2.W —
+ *     NOT the orientation of l1.W / att.W (the bundled models are not converged: +-0.01 BCE either way).
  *
  * Citation prefixes:  T/ = tdm/src/main/scala/com/mass/tdm/
  *                     O/ = otm/src/main/scala/com/mass/otm/
