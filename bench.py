@@ -280,30 +280,33 @@ def init_distributed():
 
 
 def make_comm(dist, rank, world, local):
-    """The library's communicator for the ranks of this job: rank 0 picks a free port and the harness broadcasts it; RCCL
-    (ncclCommInitRank over the job's GPUs) unless DM_COMM_TRANSPORT says otherwise, the host TCP transport if that fails."""
+    """The library's communicator for the ranks of this job: rank 0 picks a free port and the harness broadcasts it.  RCCL
+    (ncclCommInitRank over the job's GPUs) by default — and ONLY RCCL: a rendezvous failure is reported in the line (`comm_error`, the
+    extras that need the communicator say why they did not run) instead of quietly falling back to the host transport, whose numbers
+    would read like a scaling result.  DM_COMM_TRANSPORT=host asks for the host TCP transport explicitly (several ranks on one GPU)."""
     import socket
     from dismember_amd.comm import Comm
     dev = int(os.environ.get("DM_FORCE_DEVICE", local))
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    transport = os.environ.get("DM_COMM_TRANSPORT", "rccl")
+    port = [0]
+    if rank == 0:
+        s_ = socket.socket(); s_.bind(("", 0)); port[0] = s_.getsockname()[1]; s_.close()
+    dist.broadcast_object_list(port, src=0)
     err = None
-    for transport in (os.environ.get("DM_COMM_TRANSPORT", "rccl"), "host"):
-        port = [0]
-        if rank == 0:
-            s_ = socket.socket(); s_.bind(("", 0)); port[0] = s_.getsockname()[1]; s_.close()
-        dist.broadcast_object_list(port, src=0)
-        try:
-            c = Comm(world, rank, addr, port[0], transport, dev)
-            ok = 1
-        except Exception as ex:       # noqa: BLE001 — any failure here only costs the training extra
-            c, ok, err = None, 0, repr(ex)
-        oks = [None] * world
-        dist.all_gather_object(oks, ok)
-        if all(oks):
-            return c, transport, None
-        if c is not None:
-            c.close()
-    return None, None, err
+    try:
+        c = Comm(world, rank, addr, port[0], transport, dev)
+    except Exception as ex:       # noqa: BLE001 — any failure here only costs the extras that exchange data
+        c, err = None, repr(ex)
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    bad = [(r_, e_) for r_, e_ in enumerate(errs) if e_]
+    if not bad:
+        return c, transport, None
+    if c is not None:
+        c.close()
+    return None, None, ("the %s communicator could not be created on rank %d: %s (no silent fallback: set DM_COMM_TRANSPORT=host to run the "
+                        "exchange over the host transport)" % (transport, bad[0][0], bad[0][1]))
 
 
 def stage(msg):
@@ -321,6 +324,7 @@ def main():
     from dismember_amd import sharding
     dist, rank, world, local = init_distributed()
     comm = comm_transport = comm_err = None
+    jtm_comm_err_top = None
     torch = None
     if dist is not None:
         import torch
@@ -699,6 +703,7 @@ def main():
         if dist is not None:           # N > 1: ONE JTM.optimize sharded over the ranks inside the library (RCCL all-gathers over xGMI)
             if comm is None:
                 comm, comm_transport, jtm_comm_err = make_comm(dist, rank, world, local)
+                jtm_comm_err_top = jtm_comm_err
             jtm_comm = comm
         jtf = JTM.from_arrays(eng, items_s, codes_s, depth, row_off, row_ids, gap=2, seq_len=L, comm=jtm_comm)
         prep = time.perf_counter() - t0
@@ -1212,6 +1217,9 @@ def main():
             res_main["extra_1m_item_tree"] = small
         if train is not None:
             res_main["extra_train_step"] = train
+        if dist is not None:
+            res_main["comm_transport"] = comm_transport
+            res_main["comm_error"] = comm_err or jtm_comm_err_top
         print(json.dumps(res_main))
     if dist is not None:
         dist.barrier()
