@@ -1084,16 +1084,32 @@ static bool use_f64_beam(const dm_ctx *h) {
   return h->dtype == DM_F64 && (h->scorer_mode == DM_SCORER_AUTO || h->scorer_mode == DM_SCORER_F64);
 }
 
+// Histories of 17 .. 32 positions run inside the fused LDS-fed kernel (two key tiles, beam_kernel.hip.inc) whenever its frontier fits
+// LDS beside the second key tile; the per-level pipelines (tdm_pipeline.hip.inc, otm64.hip.inc) remain for beams beyond that and for
+// A/B runs (DM_LONG_PIPELINE=1).
+static bool long_history_pipeline(const dm_ctx *h, int max_beam, int L) {
+  if (L <= DM_MAXL) return false;
+  const char *e_ = getenv("DM_LONG_PIPELINE");          // read per call: the tests run both routes in one process
+  if (e_ && e_[0] == '1') return true;
+  int cap = ((2 * max_beam + 15) / 16) * 16;
+  if (cap < 32) cap = 32;
+  int pcap = 16;
+  while (pcap < cap) pcap <<= 1;
+  // (sized for the split scorer's layout; the fp32-input layout of the same request is no larger)
+  return dm_beam_lds(h->embed, 1, cap, pcap, 4, true, 2).total > 160 * 1024;
+}
+
 static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, bool tdm, SearchPlan *pl) {
   int cap = ((2 * max_beam + 15) / 16) * 16;
   if (cap < 32) cap = 32;
   int pcap = 16;
   while (pcap < cap) pcap <<= 1;
-  const int kq = (L + 3) / 4;
+  const int kt = L > DM_MAXL ? 2 : 1;          // histories of 17 .. 32 positions: the LDS-fed kernel's two-key-tile instance
+  const int kq = kt > 1 ? 4 : (L + 3) / 4;
   int nteams = 0;
   pl->wkernel = false;
   h->call_split = split_for_call(h, U, max_beam);
-  if (h->call_split && h->beam_w) {
+  if (h->call_split && h->beam_w && kt == 1) {
     // split-fp16 scorer: one-wave teams, four per workgroup, W1a in registers; falls back when the frontier outgrows LDS
     BeamWLds l = dm_beamw_lds(h->embed, cap, pcap, kq);
     if (l.total <= 160 * 1024) { nteams = DMW_NWAVES; pl->lds = l.total; pl->wkernel = true; }
@@ -1103,7 +1119,7 @@ static int plan_search(dm_ctx *h, int max_beam, int64_t U, int L, int n_levels, 
   // chain sort -> expand -> gather -> score of a level, and eight users per CU in flight instead of four
   if (!nteams)
   for (int cand = (pcap <= 256 ? 8 : 4); cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, h->call_split);
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, h->call_split, kt);
     if (l.total <= 160 * 1024) { nteams = cand; pl->lds = l.total; break; }
   }
   if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "beam too large for the LDS frontier (about 2*beam*28 bytes + weights must fit 160 KiB)");
@@ -1138,14 +1154,17 @@ static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b) {
   return DM_OK;
 }
 
-template <int E, int KQ, bool SPLIT>
+template <int E, int KQ, bool SPLIT, int KT = 1>
 static int launch_beam_EK(dm_ctx *h, const BeamParams &p_in, const SearchPlan &pl) {
   BeamParams p = p_in;
   p.static_users = (p.mode != 2 && !p.user_list && p.U <= (int64_t)pl.grid * pl.nteams) ? 1 : 0;
-  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
-  if (h->ev_next_kind == 0) snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_kernel<%d, %d, %s>", E, KQ, SPLIT ? "true" : "false");
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_beam_kernel<E, KQ, SPLIT, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds));
+  if (h->ev_next_kind == 0) {
+    if (KT == 1) snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_kernel<%d, %d, %s>", E, KQ, SPLIT ? "true" : "false");
+    else snprintf(h->last_kernel, sizeof(h->last_kernel), "dm_beam_kernel<%d, %d, %s, %d>", E, KQ, SPLIT ? "true" : "false", KT);
+  }
   if (h->ev_skip && !h->time_direct) {       // single-request path: the launch and nothing else
-    hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+    hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT, KT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
     HIPCHK(h, hipGetLastError());
     return DM_OK;
   }
@@ -1153,7 +1172,7 @@ static int launch_beam_EK(dm_ctx *h, const BeamParams &p_in, const SearchPlan &p
   int rc = next_events(h, &e0, &e1);
   if (rc != DM_OK) return rc;
   HIPCHK(h, hipEventRecord(e0, h->stream));
-  hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
+  hipLaunchKernelGGL((dm_beam_kernel<E, KQ, SPLIT, KT>), dim3(pl.grid), dim3(DM_BLOCK), pl.lds, h->stream, p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(e1, h->stream));
   return DM_OK;
@@ -1184,6 +1203,7 @@ static int launch_beam_w_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl)
 
 template <int E, bool SPLIT>
 static int launch_beam_E(dm_ctx *h, const BeamParams &p, const SearchPlan &pl) {
+  if (p.L > DM_MAXL) return launch_beam_EK<E, 4, SPLIT, 2>(h, p, pl);          // 17 .. 32 history positions: two key tiles
   switch ((p.L + 3) / 4) {
     case 1: return launch_beam_EK<E, 1, SPLIT>(h, p, pl);
     case 2: return launch_beam_EK<E, 2, SPLIT>(h, p, pl);
@@ -1486,8 +1506,8 @@ static int tdm_search_dev(dm_ctx *h, const int32_t *d_seq, int64_t U, int L, con
   if (U == 0) return DM_OK;          // an empty batch is not an error
   if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: tree codes exceed the embedding table (embeddingLookup would fail)");
   if (h->max_code >= h->num_index) return fail(h, DM_ERR_INDEX, "tdm beam search: id map codes exceed the embedding table");
-  if (L > DM_MAXL) {
-    // histories of 17 .. 32 positions: the per-level pipeline (tdm_pipeline.hip.inc); the fused kernels hold one 16-position score tile
+  if (long_history_pipeline(h, max_beam, L)) {
+    // histories of 17 .. 32 positions whose frontier does not fit LDS beside two key tiles: the per-level pipeline (tdm_pipeline.hip.inc)
     if (direct) { *direct = false; return DM_OK; }          // (the caller takes the staged path and comes back)
     HIPCHK(h, hipMemsetAsync(d_ids, 0xFF, (size_t)U * o->topk * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(d_scores, 0, (size_t)U * o->topk * 4, h->stream));
@@ -1671,7 +1691,7 @@ static int tdm_search_host(dm_ctx *h, const int32_t *seq, int64_t U, int L, cons
     }
     if (hipMemcpyAsync(d_seq, staged ? (const void *)h->h_stage : (const void *)seq, (size_t)U * L * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(h, DM_ERR_HIP, "upload failed"); break; }
     int64_t coff_[18];
-    const int n_chunks = (staged || coff || tn || L > DM_MAXL) ? 1 : host_pipe_plan((size_t)opts->topk * 8, U, coff_);
+    const int n_chunks = (staged || coff || tn || long_history_pipeline(h, mb, L)) ? 1 : host_pipe_plan((size_t)opts->topk * 8, U, coff_);
     if (n_chunks > 1) {
       if ((rc = host_pipe_ensure(h, n_chunks)) != DM_OK) break;
       int launched = 0;
@@ -1808,7 +1828,7 @@ int dm_otm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_codes, int64_t U,
   if (U == 0) return DM_OK;
   if (!d_seq_codes || !d_out_node_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
-  if (use_f64_beam(h) || L > DM_MAXL) {      // (histories of 17 .. 32 positions: the per-level pipeline in the model's type)
+  if (use_f64_beam(h) || long_history_pipeline(h, beam, L)) {      // (long histories beyond the fused kernel's LDS: the per-level pipeline in the model's type)
     return otm64_search_dev(h, d_seq_codes, U, L, beam, leaf_level, d_out_node_ids, nullptr, d_out_scores, d_out_counts, 0, 0, nullptr,
                             nullptr, nullptr, nullptr);
   }
@@ -1903,7 +1923,7 @@ int dm_otm_beam_search(dm_handle_t h, const int32_t *seq_codes, int64_t U, int L
                        int32_t *out_node_ids, float *out_scores, int32_t *out_counts) {
   if (!h) return DM_ERR_INVALID;
   DM_CLONE_ENTER(h);
-  if (use_f64_beam(h) || L > DM_MAXL)      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
+  if (use_f64_beam(h) || long_history_pipeline(h, beam, L))      // f64 weights: the reference's arithmetic (otm64.hip.inc), scores rounded to float on the way out
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, 0, nullptr, nullptr, nullptr, nullptr);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, 0, nullptr, nullptr, nullptr);
 }
@@ -1914,7 +1934,7 @@ int dm_otm_beam_search_trace(dm_handle_t h, const int32_t *seq_codes, int64_t U,
   if (!h) return DM_ERR_INVALID;
   DM_CLONE_ENTER(h);
   if (max_levels <= 0 || !trace_codes || !trace_scores || !trace_counts) return fail(h, DM_ERR_INVALID, "dm_otm_beam_search_trace: bad trace arguments");
-  if (use_f64_beam(h) || L > DM_MAXL)
+  if (use_f64_beam(h) || long_history_pipeline(h, beam, L))
     return otm64_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, nullptr, out_scores, out_counts, max_levels, trace_codes,
                              nullptr, trace_scores, trace_counts);
   return otm_search_host(h, seq_codes, U, L, beam, leaf_level, out_node_ids, out_scores, out_counts, max_levels, trace_codes,
@@ -1929,18 +1949,19 @@ int dm_tdm_bruteforce_topk(dm_handle_t h, const int32_t *seq_item_ids, int64_t U
   if (!h) return DM_ERR_INVALID;
   DM_CLONE_ENTER(h);
   if (!h->tree_loaded || !h->ids_loaded || !h->w_loaded) return fail(h, DM_ERR_STATE, "dm_tdm_bruteforce_topk: tree, id maps and weights must be loaded first");
-  if (U == 0 && L > 0 && L <= DM_MAXL && topk > 0 && topk <= 256) return DM_OK;          // an empty batch is not an error
-  if (!seq_item_ids || !out_item_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_MAXL || topk <= 0 || topk > 256)
-    return fail(h, DM_ERR_INVALID, "dm_tdm_bruteforce_topk: bad arguments (topk must be 1..256)");
+  if (U == 0 && L > 0 && L <= DM_PIPE_MAXL && topk > 0 && topk <= 256) return DM_OK;          // an empty batch is not an error
+  if (!seq_item_ids || !out_item_ids || !out_scores || !out_counts || U <= 0 || L <= 0 || L > DM_PIPE_MAXL || topk <= 0 || topk > 256)
+    return fail(h, DM_ERR_INVALID, "dm_tdm_bruteforce_topk: bad arguments (L must be 1..32, topk 1..256)");
   if (h->n_slots > h->num_index) return fail(h, DM_ERR_INDEX, "dm_tdm_bruteforce_topk: tree codes exceed the embedding table");
   HIPCHK(h, hipSetDevice(h->device));
   const int pcap = 512;
   const int chunk = ((pcap - topk) / 16) * 16;
   const int cap = chunk < 32 ? 32 : chunk;
-  const int kq = (L + 3) / 4;
+  const int kt = L > DM_MAXL ? 2 : 1;
+  const int kq = kt > 1 ? 4 : (L + 3) / 4;
   int nteams = 0, lds = 0;
   for (int cand = 4; cand >= 1; cand >>= 1) {
-    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq);
+    BeamLds l = dm_beam_lds(h->embed, cand, cap, pcap, kq, false, kt);
     if (l.total <= 160 * 1024) { nteams = cand; lds = l.total; break; }
   }
   if (!nteams) return fail(h, DM_ERR_UNSUPPORTED, "dm_tdm_bruteforce_topk: LDS budget exceeded");

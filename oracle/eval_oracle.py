@@ -72,3 +72,69 @@ def evaluate(tree, din, sequences, labels, users, user_consumed, loss_batches, t
             res.add_metrics(compute_metrics(rec, labels[j]))
         total = total + res
     return total
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OTM evaluator restatement — O/ = /root/reference/otm/src/main/scala/com/mass/otm/
+#   all_nodes        O/dataset/LocalDataSet.scala:199-205 (getAllNodes)
+#   evaluate_otm     O/evaluation/Evaluator.scala:29-84 + computeLoss :86-96, Metrics.scala:7-31, EvalResult.scala:3-27;
+#                    the search of one sample = CandidateSearcher.beamSearch through the C restatement (pyoracle.otm_beam_search)
+# Parity status: unpinned (the reference's OtmModelTrainSpec only prints these numbers); follows the source line by line.
+
+def all_nodes(ids):
+    ids = [int(i) for i in ids]
+    n = len(ids)
+    leaf_level = 0
+    while (1 << leaf_level) < n:                 # upperLog2
+        leaf_level += 1
+    res = set()
+    for i in ids:
+        a = i
+        res.add(a)
+        for _ in range(leaf_level):
+            a = int((a - 1) / 2)                 # Scala Int division truncates toward zero
+            res.add(a)
+    return res
+
+
+def evaluate_otm(search, sequences, labels, users, user_consumed, allowed, topk, total_eval_batch_size, beam_size, thread_num=1):
+    """search(seq_codes) -> (node ids, f64 scores) of the leaf level in the reference's order."""
+    n_all = len(sequences)
+    batch = max(1, total_eval_batch_size // (beam_size * 2))
+    total_loss, tp, tr, tn = 0.0, 0.0, 0.0, 0.0
+    for off in range(0, n_all, batch):
+        idx = list(range(off, min(n_all, off + batch)))
+        tds = int(math.ceil(len(idx) / float(thread_num)))
+        for c0 in range(0, len(idx), tds):
+            preds, labs = [], []
+            for j in idx[c0:c0 + tds]:
+                ids, sc = search(sequences[j])
+                consumed = set(int(x) for x in user_consumed[int(users[j])])
+                nodes = [(int(i), float(s)) for i, s in zip(ids, sc) if int(i) not in consumed and int(i) in allowed]
+                nodes = sorted(nodes, key=lambda t: -t[1])[:topk]          # Python's sort is stable, like sortBy
+                tset = [int(t) for t in labels[j]]
+                preds += [s for _, s in nodes]
+                labs += [1.0 if i in tset else 0.0 for i, _ in nodes]
+                m = compute_metrics([i for i, _ in nodes], tset)
+                tp += m[0]; tr += m[1]; tn += m[2]
+            a = b = 0.0
+            for x, z in zip(preds, labs):
+                a += max(x, 0.0) + math.log(math.exp(-abs(x)) + 1.0)
+                b += x * z
+            total_loss += a - b
+    return total_loss / n_all, (tp / n_all, tr / n_all, tn / n_all)
+
+
+# Deep-Retrieval evaluator restatement — D/ = /root/reference/deep-retrieval/src/main/scala/com/mass/dr/
+#   evaluate_dr_metrics   D/evaluation/Evaluator.scala:41-70 (the metrics fold) + recommendItems :108-129, Metrics.scala:5-27
+def evaluate_dr_metrics(dr, sequences, labels, users, user_consumed, topk, beam_size):
+    p = r = g = 0.0
+    for j in range(len(sequences)):
+        consumed = set(int(x) for x in user_consumed[int(users[j])])
+        paths, _ = dr.beam_search(sequences[j], beam_size)
+        cands = [int(c) for c in dr.search_candidates(paths) if int(c) not in consumed]
+        scores = dr.rerank(cands, sequences[j]) if cands else []
+        order = sorted(range(len(cands)), key=lambda i: -scores[i])[:topk]
+        m = compute_metrics([cands[i] for i in order], [int(t) for t in labels[j]])
+        p += m[0]; r += m[1]; g += m[2]
+    return p, r, g

@@ -21,6 +21,7 @@ struct JNINativeInterface_ {
   const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
   void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
   jobject (*GetObjectArrayElement)(JNIEnv *, jobjectArray, jsize);
+  jsize (*GetArrayLength)(JNIEnv *, jarray);
   jdouble *(*GetDoubleArrayElements)(JNIEnv *, jdoubleArray, jboolean *);
   void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
   jfloat *(*GetFloatArrayElements)(JNIEnv *, jfloatArray, jboolean *);

@@ -93,3 +93,76 @@ def test_evaluate_vs_oracle(fixture_tree, fixture_w32, oracle, oracle_tree):
     assert (np.abs(got - want) <= bound + 1e-12).all(), (got, want, bound)
     if diff_users == 0:
         assert (res.precision, res.recall, res.ndcg) == pytest.approx((ores.precision, ores.recall, ores.ndcg), rel=1e-12)
+
+
+def test_otm_dr_eval_helpers():
+    # getAllNodes: leaves 7..10 of a 4-leaf mapping (leafLevel 2) -> the leaves and two levels of ancestors
+    assert ev.all_nodes([7, 8, 9, 10]) == eo.all_nodes([7, 8, 9, 10]) == {7, 8, 9, 10, 3, 4, 1}
+    assert ev.all_nodes([3, 4, 5]) == eo.all_nodes([3, 4, 5]) == {3, 4, 5, 1, 2, 0}
+    x, z = np.array([0.0, 2.0, -3.0]), np.array([1.0, 0.0, 1.0])
+    exp = math.log(2) + (2 + math.log1p(math.exp(-2))) + math.log1p(math.exp(-3)) - (-3.0)
+    assert ev.bce_with_logits_sum(x, z) == pytest.approx(exp, rel=1e-14)
+    assert ev.bce_with_logits_sum([], []) == 0.0
+    r = ev.OtmEvalResult(1.0, 0.5, 0.25) + ev.OtmEvalResult(1.0, 0.5, 0.25)
+    assert str(r / 4) == "{precision: 0.500000, recall: 0.250000, ndcg: 0.125000}"
+    d = ev.DrEvalResult([1.0, 2.5], 3.0, 1.0, 2.0, 3.0, 4) + ev.DrEvalResult([1.0, 0.5], 1.0, 1.0, 0.0, 1.0, 4)
+    assert str(d) == "eval layer loss: [1, 1.5], rerank loss: 2.0000\n\t\tprecision: 0.250000, recall: 0.250000, ndcg: 0.500000"
+    m = d.mean_metrics()
+    assert (m.layer_loss, m.rerank_loss, m.precision, m.size, m.count) == ([1.0, 1.5], 2.0, 0.25, 8, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thread_num", [1, 3])
+def test_evaluate_otm_vs_oracle(oracle, thread_num):
+    """Evaluator.evaluate of the OTM module (otm/.../evaluation/Evaluator.scala:29-84) on an fp64 model: the device evaluator's
+    per-sample lists are the fp64 oracle's (the search is node-for-node equal), so metrics are equal and the loss sum agrees to
+    the scores' 1e-9."""
+    from dismember_amd import Engine
+    from helpers import random_din_weights
+    rng = np.random.default_rng(31)
+    E, L, leaf_level, beam, topk, N = 32, 10, 8, 12, 7, 37
+    NI = (1 << (leaf_level + 1)) - 1
+    w = random_din_weights(rng, E, NI, dtype=np.float64, std=0.2, bias_std=0.1)
+    eng = Engine(0)
+    eng.load_weights_din(w, E, NI)
+    odin = oracle.Din(w, E, L, NI)
+    first = (1 << leaf_level) - 1
+    leaves = first + rng.permutation(1 << leaf_level)[:200]                   # 200 mapped items of the 256 leaves
+    allowed = ev.all_nodes(leaves)
+    assert allowed == eo.all_nodes(leaves)
+    seqs = rng.choice(leaves, size=(N, L)).astype(np.int32)
+    seqs[rng.random((N, L)) < 0.2] = -1
+    labels = [rng.choice(leaves, size=int(rng.integers(1, 9)), replace=False).tolist() for _ in range(N)]
+    users = rng.integers(0, 9, size=N)
+    consumed = {u: rng.choice(leaves, size=int(rng.integers(3, 40)), replace=False) for u in range(9)}
+    loss, res = ev.evaluate_otm(eng, seqs, labels, users, consumed, allowed, leaf_level, topk, total_eval_batch_size=240,
+                                beam_size=beam, thread_num=thread_num)
+    oloss, ores = eo.evaluate_otm(lambda s: oracle.otm_beam_search(odin, s, leaf_level, beam), seqs, labels, users, consumed, allowed,
+                                  topk, 240, beam, thread_num=thread_num)
+    assert (res.precision, res.recall, res.ndcg) == pytest.approx(ores, rel=1e-12, abs=0)
+    assert res.recall > 0
+    assert loss == pytest.approx(oloss, rel=1e-8)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_evaluate_dr_vs_oracle():
+    """The metrics fold of the Deep-Retrieval evaluator (deep-retrieval/.../evaluation/Evaluator.scala:41-70, recommendItems
+    :108-129) on an fp64 model: consumed items dropped BEFORE the re-rank cut — the device list asked for topk + |consumed|."""
+    from test_gpu_dr import make, histories
+    K, D, L, E, num_item, beam, topk, N = 30, 3, 6, 16, 400, 12, 10, 33
+    eng, orc, w, rng = make(K, D, L, E, num_item, 5, np.float64)
+    seqs = histories(rng, N, L, num_item)
+    users = rng.integers(0, 7, size=N)
+    consumed = {u: rng.choice(num_item, size=int(rng.integers(1, 120)), replace=False) for u in range(7)}
+    labels = [rng.choice(num_item, size=int(rng.integers(1, 12)), replace=False).tolist() for _ in range(N)]
+    ids0, _, cnt0 = eng.dr_recommend(seqs, beam, 40)
+    for u in range(0, N, 2):                                      # every other sample: labels the search can find (some consumed, some not)
+        if cnt0[u] > 3:
+            labels[u] = ids0[u, [0, 2, cnt0[u] - 1]].tolist() + labels[u][:2]
+    res = ev.evaluate_dr(eng, seqs, labels, users, consumed, topk, beam, batch_size=10, num_layer=D)
+    op, or_, og = eo.evaluate_dr_metrics(orc, seqs, labels, users, consumed, topk, beam)
+    assert res.size == N and res.count == 4 and res.layer_loss == [0.0] * D
+    assert (res.precision, res.recall, res.ndcg) == pytest.approx((op, or_, og), rel=1e-12, abs=0)
+    assert res.recall > 0
+    eng.close()

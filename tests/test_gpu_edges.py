@@ -61,13 +61,22 @@ def test_history_lengths_1_to_16(oracle, E, L):
     eng.close()
 
 
-@pytest.mark.parametrize("E,L", [(128, 17), (128, 24), (128, 32), (32, 20)])
-def test_history_lengths_17_to_32_tdm(oracle, E, L):
-    """Histories longer than the fused kernels' 16-position score tile take the per-level pipeline (csrc/tdm_pipeline.hip.inc);
-    the reference has no length limit (scalann/.../nn/Attention.scala:34-53).  Same contract as every TDM search: the oracle's
-    integer logic replayed exactly on the device's per-level scores, scores within the fp32 tolerance — on a ragged tree, with
-    and without the mask, and with consumed items widening the beam (Recommender.recommendItems, Recommender.scala:18-37)."""
+@pytest.mark.parametrize("E,L,route", [(128, 17, "fused"), (128, 24, "fused"), (128, 32, "fused"), (32, 20, "fused"), (16, 29, "fused"),
+                                       (128, 24, "fused_f32"), (64, 18, "fused_f32"),
+                                       (128, 17, "pipeline"), (128, 32, "pipeline"), (32, 20, "pipeline")])
+def test_history_lengths_17_to_32_tdm(oracle, monkeypatch, E, L, route):
+    """Histories of 17 .. 32 positions run INSIDE the fused LDS-fed kernel through a second 16-position key tile
+    (dm_beam_kernel<E, 4, SPLIT, 2>, csrc/beam_kernel.hip.inc) in both scorer arithmetics; the per-level pipeline
+    (csrc/tdm_pipeline.hip.inc) remains for frontiers that do not fit LDS beside two key tiles and is forced here with
+    DM_LONG_PIPELINE=1.  The reference has no length limit (scalann/.../nn/Attention.scala:34-53).  Same contract as every TDM
+    search: the oracle's integer logic replayed exactly on the device's per-level scores, scores within the fp32 tolerance — on a
+    ragged tree, with and without the mask, and with consumed items widening the beam (Recommender.recommendItems,
+    Recommender.scala:18-37)."""
     from test_gpu_parity import replay_and_check
+    if route == "pipeline":
+        monkeypatch.setenv("DM_LONG_PIPELINE", "1")
+    else:
+        monkeypatch.delenv("DM_LONG_PIPELINE", raising=False)
     rng = np.random.default_rng(1000 * E + L)
     depth, n_items, beam = 9, 400, 24
     t = synthetic_tree(rng, depth, n_items)
@@ -76,12 +85,20 @@ def test_history_lengths_17_to_32_tdm(oracle, E, L):
     otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
     odin = oracle.Din(w, E, L, NI)
     eng = _engine(t, w, E)
+    if route == "fused_f32":
+        eng.set_scorer_mode("f32")
     seqs = random_histories(rng, t["leaf_ids"], 19, L, pad_prob=0.3)
     seqs[0] = 0                                           # all padding
     seqs[1, :] = seqs[1, 0]                               # one item repeated L times
+    seqs[2, :16] = 0                                      # only positions of the second key tile are live
+    seqs[3, 16:] = 0                                      # ... and only positions of the first
     for use_mask in (True, False):
         replay_and_check(otree, odin, eng, seqs, beam, 20, use_mask=use_mask)
-    assert "pipeline" in eng.last_beam_kernel()
+    if route == "pipeline":
+        assert "pipeline" in eng.last_beam_kernel()
+    else:
+        split = "true" if (route == "fused" and E % 32 == 0) else "false"
+        assert eng.last_beam_kernel() == "dm_beam_kernel<%d, 4, %s, 2>" % (E, split), eng.last_beam_kernel()
     replay_and_check(otree, odin, eng, seqs[:5], 300, 50)             # a beam wider than any level of the tree
     ids, sc, cnt = eng.tdm_beam_search(seqs, beam, 20)
     same = 0
@@ -107,13 +124,20 @@ def test_history_lengths_17_to_32_tdm(oracle, E, L):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,E,L,beam", [("f64", 128, 17, 33), ("f64", 64, 32, 100), ("f32", 128, 24, 33), ("f32", 128, 32, 7)])
-def test_history_lengths_17_to_32_otm(oracle, dtype, E, L, beam):
-    """OTM searches with 17..32 history positions run the per-level pipeline in the model's own type (csrc/otm64.hip.inc):
-    buildBeamNodes (otm/.../model/CandidateSearcher.scala:109-122) replayed exactly on the device's scores; fp64 models: node
-    lists equal to the fp64 oracle's and scores within 1e-10 / 1e-9; f32 models: scores within the fp32 tolerance."""
+@pytest.mark.parametrize("dtype,E,L,beam,route", [("f64", 128, 17, 33, "pipeline"), ("f64", 64, 32, 100, "pipeline"),
+                                                  ("f32", 128, 24, 33, "fused"), ("f32", 128, 32, 7, "fused"), ("f32", 32, 19, 100, "fused"),
+                                                  ("f32", 128, 24, 33, "pipeline"), ("f32", 128, 32, 7, "pipeline")])
+def test_history_lengths_17_to_32_otm(oracle, monkeypatch, dtype, E, L, beam, route):
+    """OTM searches with 17..32 history positions: f32 models run the fused LDS-fed kernel's two-key-tile instance
+    (csrc/beam_kernel.hip.inc), fp64 models (and DM_LONG_PIPELINE=1) the per-level pipeline in the model's own type
+    (csrc/otm64.hip.inc): buildBeamNodes (otm/.../model/CandidateSearcher.scala:109-122) replayed exactly on the device's scores;
+    fp64 models: node lists equal to the fp64 oracle's and scores within 1e-10 / 1e-9; f32 models: scores within the fp32 tolerance."""
     from dismember_amd import Engine
     from test_gpu_precision import _otm_replay
+    if route == "pipeline":
+        monkeypatch.setenv("DM_LONG_PIPELINE", "1")
+    else:
+        monkeypatch.delenv("DM_LONG_PIPELINE", raising=False)
     leaf_level, U = 9, 7
     rng = np.random.default_rng(E + beam + L)
     NI = (1 << (leaf_level + 1)) - 1
@@ -133,7 +157,10 @@ def test_history_lengths_17_to_32_otm(oracle, dtype, E, L, beam):
     else:
         ids, sc, cnt, tc, ts, tn = eng.otm_beam_search_trace(codes, beam, leaf_level, levels)
         tol = (ATOL, RTOL)
-    assert "pipeline" in eng.last_beam_kernel()
+    if route == "pipeline":
+        assert "pipeline" in eng.last_beam_kernel()
+    else:
+        assert eng.last_beam_kernel() == "dm_beam_kernel<%d, 4, true, 2>" % E, eng.last_beam_kernel()
     _otm_replay(oracle, tc, ts, tn, beam, start_level, leaf_level, ids)
     for u in range(U):
         for it in range(levels):

@@ -61,6 +61,46 @@ CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_kernel_timing_get",
                "dm_kernel_timing_get_kind", "dm_get_scorer_mode", "dm_comm_rank", "dm_device_count", "dm_last_scored_rows",
                "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_adam_last_step_rows", "dm_comm_unique_id", "dm_dev_alloc"}
 JTYPE = {"jint": "Int", "jlong": "Long", "jfloat": "Float", "jdouble": "Double", "jbyte": "Byte"}
+# Minimum lengths (in elements) of host arrays whose extent follows from the scalar arguments of the same call: checked with
+# GetArrayLength BEFORE anything is pinned, so that a caller mistake raises IllegalArgumentException instead of overrunning the
+# JVM heap (the C side trusts its (pointer, size) pairs).  Expressions are over the C argument names (opts_* = struct fields);
+# arrays whose extent depends on the CONTENTS of another array (CSR targets, consumed ids) are checked by the library where it can.
+_SEARCH_OUT = {"out_item_ids": "U * opts_topk", "out_scores": "U * opts_topk", "out_counts": "U"}
+_OTM_OUT = {"seq_codes": "U * L", "out_node_ids": "U * 2 * beam", "out_scores": "U * 2 * beam", "out_counts": "U"}
+EXTENTS = {
+    "dm_load_tree_tdm": {"codes": "n_nodes", "node_ids": "n_nodes", "is_leaf": "n_nodes"},
+    "dm_load_id_maps": {"leaf_item_ids": "n", "leaf_codes": "n"},
+    "dm_tdm_id_to_code": {"item_ids": "n", "codes": "n", "mask_pos": "n", "n_mask": "1"},
+    "dm_din_forward": {"codes": "B", "seqs": "B * L", "pad_flat_idx": "n_pad", "logits": "B"},
+    "dm_tdm_beam_search": dict(_SEARCH_OUT, seq_item_ids="U * L", consumed_off="U + 1"),
+    "dm_tdm_beam_search_trace": dict(_SEARCH_OUT, seq_item_ids="U * L", trace_counts="U * max_levels"),
+    "dm_otm_beam_search": _OTM_OUT, "dm_otm_beam_search_f64": _OTM_OUT,
+    "dm_otm_beam_search_trace": dict(_OTM_OUT, trace_counts="U * max_levels"),
+    "dm_otm_beam_search_trace_f64": dict(_OTM_OUT, trace_counts="U * max_levels"),
+    "dm_tdm_bruteforce_topk": {"seq_item_ids": "U * L", "out_item_ids": "U * topk", "out_scores": "U * topk", "out_counts": "U"},
+    "dm_jtm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
+    "dm_jtm_cache_rows": {"row_off": "n_items + 1"},
+    "dm_jtm_child_weights_cached": {"item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
+    "dm_jtm_step_cached": {"item_node": "n_items", "old_node": "n_items", "out_node": "n_items"},
+    "dm_jtm_optimize_cached": {"item_code": "n_items", "out_proj": "n_items"},
+    "dm_jtm_optimize_all": {"hs": "n", "item_code": "n_items", "out_proj": "n_items"},
+    "dm_jtm_rebalance": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "out_node": "n"},
+    "dm_jtm_rebalance_all": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "item_node": "n", "out_node": "n"},
+    "dm_otm_rebalance_all": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "item_node": "n", "out_node": "n"},
+    "dm_otm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
+    "dm_otm_rebalance": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "out_node": "n"},
+    "dm_train_forward_backward": {"codes": "B", "seqs": "B * L", "pad_flat_idx": "n_pad", "labels": "B", "loss": "1"},
+    "dm_comm_create_all": {"devices": "n", "out": "n"},
+    "dm_comm_allreduce_f64": {"vals": "n"},
+    "dm_otm_train_batch": {"seq_codes": "U * L", "target_off": "U + 1"},
+    "dm_otm_pseudo_targets": {"seq_codes": "U * L", "target_off": "U + 1", "out_counts": "U"},
+    "dm_tdm_set_node_probs": {"codes": "n", "probs": "n"},
+    "dm_tdm_make_train_batch": {"seq_item_ids": "T * L", "target_item_ids": "T", "neg_counts": "n_counts", "out_codes": "cap",
+                                "out_seqs": "cap * L", "out_rowmask": "cap", "out_labels": "cap", "n_rows": "1"},
+    "dm_tdm_sample_train_batch_dev": {"neg_counts": "n_counts", "n_rows": "1"},
+    "dm_dr_load_path_items": {"item_off": "n_paths + 1"},
+    "dm_allreduce_grads": {"hs": "n"},
+}
 
 
 def pin(cname, je, an, const):
@@ -175,7 +215,15 @@ def gen(protos):
                 raise SystemExit("gen_jni: cannot map argument `%s %s%s` of %s" % (base, ptr, an, cname))
         jret, sret = ("jstring", "String") if ret != "int" else (("jint", "Int") if cname in ("dm_version",) else ("void", "Unit"))
         sig = "JNIEXPORT %s JNICALL Java_com_mass_hip_Native_%s(JNIEnv *e, jclass cls%s) {" % (jret, meth.replace("_", "_1"), "".join(", " + p for p in jparams))
-        body = [sig] + pre
+        checks = []
+        names = set(a["name"] for a in args)
+        for an, expr in EXTENTS.get(cname, {}).items():
+            if an not in names:
+                raise SystemExit("gen_jni: EXTENTS names `%s`, which %s does not take" % (an, cname))
+            need = re.sub(r"\bopts_(\w+)", r"opts_\1", expr)
+            checks.append('  if (%s && (jlong)(*e)->GetArrayLength(e, %s) < (jlong)(%s)) { raise_msg(e, DM_ERR_INVALID, "%s: array `%s` is shorter than %s"); (void)cls; return; }'
+                          % (an, an, need, meth, an, expr.replace("(jlong)", "")))
+        body = [sig] + checks + pre
         if pinned:
             # the JVM could not hand out one of the arrays (an exception is already pending): give back what was acquired and
             # return to Java without calling into the library or throwing on top of it
