@@ -150,7 +150,7 @@ def test_evaluate_dr_vs_oracle():
     """The metrics fold of the Deep-Retrieval evaluator (deep-retrieval/.../evaluation/Evaluator.scala:41-70, recommendItems
     :108-129) on an fp64 model: consumed items dropped BEFORE the re-rank cut — the device list asked for topk + |consumed|."""
     from test_gpu_dr import make, histories
-    K, D, L, E, num_item, beam, topk, N = 30, 3, 6, 16, 400, 12, 10, 33
+    K, D, L, E, num_item, beam, topk, N = 5, 2, 6, 16, 400, 6, 10, 33      # 25 paths, 2 per item: every beam reaches items
     eng, orc, w, rng = make(K, D, L, E, num_item, 5, np.float64)
     seqs = histories(rng, N, L, num_item)
     users = rng.integers(0, 7, size=N)

@@ -19,9 +19,11 @@ out = {"users": U, "depth": depth, "beam": beam, "E": E}
 for L in (16, 17, 24, 32):
     seqs = synth.make_users(tree["leaf_ids"], U, L, np.random.default_rng(5))
     eng.tdm_beam_search(seqs, beam, beam)                 # warm-up at full size: the workspace is allocated here
-    t0 = time.perf_counter()
-    ids, sc, cnt = eng.tdm_beam_search(seqs, beam, beam)
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(3):                                    # best of three: the first timed call of a route still pays one-time set-up
+        t0 = time.perf_counter()
+        ids, sc, cnt = eng.tdm_beam_search(seqs, beam, beam)
+        dt = min(dt, time.perf_counter() - t0)
     out["tdm_L%d" % L] = {"kernel": eng.last_beam_kernel(), "ms": round(dt * 1e3, 2), "users_per_s": round(U / dt), "rows": eng.last_scored_rows()}
 eng.close()
 # OTM in fp64 on a complete tree
