@@ -138,6 +138,7 @@ def parse():
     ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=1024, help="users for recall@topk vs brute force (0 skip)")
     ap.add_argument("--diverse", type=int, default=1, help="also time the headline search on beams that DIVERGE (attention path x1.7, embeddings x32) and on an iid (rho 0) table; 0 = skip")
+    ap.add_argument("--long-history", type=int, default=1, help="also time the headline search with 24-position histories (fused two-key-tile kernel vs the per-level pipeline); 0 = skip")
     ap.add_argument("--host-buffer-steps", type=int, default=3, help="steps of the headline workload through the host-buffer entry point (0 = skip)")
     ap.add_argument("--jtm-full", type=int, default=1, help="also time the FULL JTM.optimize over the 10M-item catalogue (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--jtm-rows", type=int, default=4, help="training rows per item of the full JTM.optimize extra")
@@ -467,6 +468,40 @@ def main():
                  "identical_id_lists_vs_headline": "%d/%d" % (int(same_rows.sum()), U),
                  "max_abs_score_diff_on_identical_lists": float(dsc.max()) if dsc.size else None,
                  "max_abs_score": float(np.abs(sc).max())}
+
+    stage("extra histories of 24 positions (the fused two-key-tile kernel)")
+    # ---- extra: the headline search with histories of 24 positions (round-4 verdict, next #8): seq_len 17 .. 32 runs inside the fused LDS-fed
+    # kernel through a second 16-position key tile (dm_beam_kernel<E, 4, SPLIT, 2>); DM_LONG_PIPELINE=1 = round 4's per-level pipeline.
+    long_hist = None
+    if a.long_history and rank == 0:
+        L2_, U2_ = 24, min(U, 32768)
+        seqs24 = synth.make_users(tree["leaf_ids"], U2_, L2_, np.random.default_rng(synth.SEED + 77))
+        d_s24 = eng.dev_alloc(U2_ * L2_ * 4)
+        eng.h2d(d_s24, seqs24)
+        long_hist = {"seq_len": L2_, "users_per_step": U2_, "what": "the headline tree, table and beam with 24-position histories, device-resident request"}
+        for key, envv in (("fused", None), ("per_level_pipeline", "1")):
+            if envv is None: os.environ.pop("DM_LONG_PIPELINE", None)
+            else: os.environ["DM_LONG_PIPELINE"] = envv
+            eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
+            sync()
+            n24 = 3 if envv is None else 1
+            t0 = time.perf_counter()
+            for _ in range(n24):
+                eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
+            sync()
+            dt24 = (time.perf_counter() - t0) / n24
+            long_hist[key] = {"kernel": eng.last_beam_kernel(), "ms_per_step": dt24 * 1e3, "users_per_s": U2_ / dt24, "scored_rows": eng.last_scored_rows()}
+            if envv is None:
+                i24 = np.empty((U2_, a.topk), np.int32); eng.d2h(i24, d_ids)
+            else:
+                j24 = np.empty((U2_, a.topk), np.int32); eng.d2h(j24, d_ids)
+                long_hist["identical_id_lists_fused_vs_pipeline"] = "%d/%d" % (int((i24 == j24).all(axis=1).sum()), U2_)
+        os.environ.pop("DM_LONG_PIPELINE", None)
+        long_hist["fused_over_headline_rate"] = long_hist["fused"]["users_per_s"] / (U * a.steps / dt)      # (per GPU, L = 24 against the headline L)
+        eng.dev_free(d_s24)
+        eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)      # (restore shard 0's results in the output buffers)
+        sync()
+    barrier()
 
     stage("extra the headline search on beams that diverge / on an iid table")
     # ---- extra: the same search where the users' beams DIVERGE (round-4 verdict, next #2).  With the reference's init the history term of the
@@ -1205,6 +1240,9 @@ def main():
             res_main["extra_config0_latency"] = c1
         if other is not None:
             res_main["extra_other_scorer"] = other
+        if long_hist is not None:
+            res_main["extra_long_history"] = long_hist
+            res_main["long_history_L24_users_per_s"] = long_hist["fused"]["users_per_s"]
         if otm is not None:
             res_main["extra_otm_serve"] = otm
         if jtm is not None:

@@ -824,7 +824,7 @@ def test_otm_train_batch_vs_oracle(fixture_w64, fixture_otm_mapping, oracle, dty
 
 def test_otm_train_batch_long_history_f32(oracle):
     """The same iteration on an f32 model with 20 history positions (round-4 advisor finding: the trainer used to hand such batches to the
-    fused f32 search and to the 16-position rows kernel, which truncate the history): beam nodes from the per-level pipeline, pseudo
+    fused f32 search and to the 16-position rows kernel, which truncated the history): beam nodes from a search that sees all 20 positions, pseudo
     targets through the general forward, the training kernel's 32-position instantiation.  Scores of the returned beam nodes against
     the oracle's forward on the FULL history, per-level losses against the oracle's replay of the device's own lists (f32 contract)."""
     from dismember_amd import Engine
@@ -844,7 +844,7 @@ def test_otm_train_batch_long_history_f32(oracle):
     targets = [(first + rng.choice(1 << leaf_level, int(rng.integers(1, 4)), replace=False)).tolist() for _ in range(U)]
     odin = oracle.Din(w.copy(), E, L, NI)
     got = tr.beam_search_nodes(codes)
-    assert "pipeline" in eng.last_beam_kernel()
+    assert eng.last_beam_kernel() == "dm_beam_kernel<32, 4, true, 2>", eng.last_beam_kernel()      # (round 5: the fused two-key-tile kernel)
     for lv in range(len(got)):
         for u in range(U):
             nodes = np.array([n for n, _ in got[lv][u]], np.int32)
