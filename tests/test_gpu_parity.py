@@ -307,17 +307,19 @@ def test_otm_beam_search_vs_oracle_f64(fixture_w64, oracle, oracle_din64, fixtur
 
 
 # --------------------------------------------------------------------------- brute force (recall oracle)
-@pytest.mark.parametrize("E,depth,n_items,topk", [(128, 11, 1500, 200), (16, 9, 300, 50), (64, 12, 4000, 256)])
-def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk):
-    """Every leaf scored by the fused kernel == the oracle scorer on every leaf; top-k by (score desc, code asc)."""
-    rng = np.random.default_rng(4242 + E)
+@pytest.mark.parametrize("E,depth,n_items,topk,L", [(128, 11, 1500, 200, 10), (16, 9, 300, 50, 10), (64, 12, 4000, 256, 10),
+                                                     (128, 10, 700, 100, 24), (32, 9, 300, 40, 17)])
+def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk, L):
+    """Every leaf scored by the fused kernel == the oracle scorer on every leaf; top-k by (score desc, code asc).  L = 17 .. 32: the
+    kernel's two-key-tile instance (round 5)."""
+    rng = np.random.default_rng(4242 + E + L)
     t = synthetic_tree(rng, depth, n_items)
     NI = (1 << (depth + 1)) - 1
     w = random_din_weights(rng, E, NI)
     eng = make_engine(t, w, E)
-    odin = oracle.Din(w, E, 10, NI)
+    odin = oracle.Din(w, E, L, NI)
     otree = oracle.TdmTree(t["codes"], t["ids"], t["is_leaf"], t["leaf_ids"], t["leaf_codes"], t["max_level"])
-    seqs = random_histories(rng, t["leaf_ids"], 7, 10)
+    seqs = random_histories(rng, t["leaf_ids"], 7, L)
     seqs[1] = 0
     ids, sc, cnt = eng.tdm_bruteforce_topk(seqs, topk)
     k = min(topk, n_items)
@@ -325,7 +327,7 @@ def test_bruteforce_topk_vs_oracle(oracle, E, depth, n_items, topk):
     for u in range(seqs.shape[0]):
         assert cnt[u] == k
         seq_codes, mask = otree.id_to_code(seqs[u])
-        pad = (mask[None, :] + (np.arange(n_items) * 10)[:, None]).reshape(-1)
+        pad = (mask[None, :] + (np.arange(n_items) * L)[:, None]).reshape(-1)
         ref = odin.forward(t["leaf_codes"], np.tile(seq_codes, (n_items, 1)), pad)
         gpu_by_id = dict(zip(ids[u, :k].tolist(), sc[u, :k].tolist()))
         ref_by_id = {lut[int(c)]: float(s) for c, s in zip(t["leaf_codes"], ref)}
