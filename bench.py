@@ -764,6 +764,7 @@ def main():
                     "scoring_s": tim.get("scoring_s"), "rebalance_s": tim.get("rebalance_s"), "host_glue_s": tim.get("host_glue_s"),
                     "rebalance": "on the device (dm_jtm_optimize_cached: weights and projection stay in HBM)" if tim.get("fused_step_s") else "host",
                     "rows_upload_s": tim.get("rows_upload_s"),
+                    "rows_uploaded_by_this_rank": tim.get("rows_uploaded"), "rows_total": int(jtf.row_off[-1]),     # a rank uploads its item range's rows only
                     "synthetic_catalogue_generation_s": prep,
                     "note_on_preparation": "`seconds` covers the whole JTM.optimize call: the upload of the catalogue's training rows (rows_upload_s; the "
                                            "per-row history codes are built on the device once per call), twelve gap steps of scoring + re-balance, the download "

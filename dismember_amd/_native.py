@@ -72,6 +72,8 @@ SIGNATURES = {
     "dm_jtm_child_weights": (C.c_int, [C.c_void_p, i64p, i32p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, f32p]),
     "dm_jtm_cache_rows": (C.c_int, [C.c_void_p, i64p, i32p, C.c_int64, C.c_int]),
+    "dm_jtm_cache_rows_range": (C.c_int, [C.c_void_p, i64p, i32p, C.c_int64, C.c_int, C.c_int64, C.c_int64]),
+    "dm_jtm_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, i64p, i64p]),
     "dm_jtm_child_weights_cached": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
     "dm_jtm_last_step_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dm_jtm_optimize_cached": (C.c_int, [C.c_void_p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_double)]),

@@ -107,8 +107,15 @@ class JTM:
         t_sc = t_rb = t_host = 0.0
         t0 = time.perf_counter()
         if weight_fn is None and self.row_off[0] == 0:         # itemSequenceMap goes to the device once for all gap steps
-            self.engine._chk(N.lib().dm_jtm_cache_rows(self.engine._h, _p(self.row_off, N.i64p), _p(self.row_ids, N.i32p), self.items.size, self.L))
+            lo, hi = 0, int(self.items.size)
+            if self.comm is not None and hasattr(self.comm, "_c") and self.comm.world > 1 and os.environ.get("DM_JTM_FUSED", "1") not in ("0", "step"):
+                # a rank of a sharded run only scores its item range (dm_jtm_shard_range): only that range's rows go up
+                a_, b_ = C.c_int64(0), C.c_int64(0)
+                self.engine._chk(N.lib().dm_jtm_shard_range(self.items.size, self.comm.rank, self.comm.world, C.byref(a_), C.byref(b_)))
+                lo, hi = a_.value, b_.value
+            self.engine._chk(N.lib().dm_jtm_cache_rows_range(self.engine._h, _p(self.row_off, N.i64p), _p(self.row_ids, N.i32p), self.items.size, self.L, lo, hi))
             self._cached = True
+            self._cached_rows = int(self.row_off[hi] - self.row_off[lo])
         t_up = time.perf_counter() - t0
         try:
             lib_comm = self.comm is None or hasattr(self.comm, "_c")     # None, or the library's own communicator (not a test adapter)
@@ -123,7 +130,7 @@ class JTM:
                 self.engine._chk(N.lib().dm_jtm_optimize_cached(self.engine._h, _p(self.item_code, N.i32p), self.items.size, self.max_level, self.gap,
                                                                 int(self.hierarchical), self.min_level, int(self.use_mask), _p(out, N.i32p), secs))
                 if timing is not None:
-                    timing.update(scoring_s=secs[0], rebalance_s=secs[1], host_glue_s=0.0, rows_upload_s=t_up, fused_step_s=time.perf_counter() - t1,
+                    timing.update(scoring_s=secs[0], rebalance_s=secs[1], host_glue_s=0.0, rows_upload_s=t_up, rows_uploaded=self._cached_rows, fused_step_s=time.perf_counter() - t1,
                                   sharding=self.optimize_stats())
                 return out if as_array else dict(zip(self.items.tolist(), out.tolist()))
             return self._optimize(proj, weight_fn, timing, as_array, t_up)

@@ -373,12 +373,17 @@ class JTM {
     return res;
   }
   // one process, several GPUs: engines[i] carries rank i of a dm_comm_create_all clique (engines[0] may be this object's engine);
-  // every engine gets the catalogue's rows, the ranks run on host threads inside the call and must end with the same projection
+  // every engine gets the rows of ITS item range, the ranks run on host threads inside the call and must end with the same projection
   std::map<int32_t, int32_t> optimizeAll(const std::vector<Engine *> &engines) {
     const size_t n = items_.size();
     std::vector<int32_t> proj(n, 0);
     std::vector<dm_handle_t> hs;
-    for (Engine *e : engines) { e->check(dm_jtm_cache_rows(e->handle(), rowOff_.data(), rowIds_.data(), (int64_t)n, L_)); hs.push_back(e->handle()); }
+    for (size_t r = 0; r < engines.size(); r++) {             // every rank: the bookkeeping of all items, the ROWS of the range it scores
+      int64_t lo = 0, hi = 0;
+      engines[r]->check(dm_jtm_shard_range((int64_t)n, (int)r, (int)engines.size(), &lo, &hi));
+      engines[r]->check(dm_jtm_cache_rows_range(engines[r]->handle(), rowOff_.data(), rowIds_.data(), (int64_t)n, L_, lo, hi));
+      hs.push_back(engines[r]->handle());
+    }
     struct Drop { const std::vector<Engine *> &es; int L; ~Drop() { for (Engine *e : es) dm_jtm_cache_rows(e->handle(), nullptr, nullptr, 0, L); } } drop{engines, L_};
     engines.at(0)->check(dm_jtm_optimize_all(hs.data(), (int)hs.size(), itemCode_.data(), (int64_t)n, maxLevel_, gap_, hier_ ? 1 : 0, minLevel_,
                                              useMask_ ? 1 : 0, proj.data(), nullptr));

@@ -202,6 +202,13 @@ int dm_jtm_child_weights(dm_handle_t h, const int64_t *row_off, const int32_t *r
  * (n_items == 0 drops the copy); dm_jtm_child_weights_cached scores the items [i_lo, i_lo + n_items) of that catalogue
  * (item_node and weights are indexed from i_lo: a rank's item shard) and uploads nothing but item_node. */
 int dm_jtm_cache_rows(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, int64_t n_items, int L);
+/* Sharded runs (one handle per rank, dm_jtm_optimize_cached with a communicator attached / dm_jtm_optimize_all): a rank only ever scores
+ * the items [i_lo, i_hi) that dm_jtm_shard_range(n_items, rank, nranks, ...) gives it (the reference's contiguous split of the items
+ * over its workers, JTM.scala:47-52).  dm_jtm_cache_rows_range takes the SAME full arrays and keeps row_off for all items, but uploads
+ * only that range's training rows — the upload, the row arrays and the per-row history codes then scale with 1 / nranks.  Scoring items
+ * outside the range on such a handle is DM_ERR_STATE. */
+int dm_jtm_shard_range(int64_t n_items, int rank, int nranks, int64_t *i_lo, int64_t *i_hi);
+int dm_jtm_cache_rows_range(dm_handle_t h, const int64_t *row_off, const int32_t *row_item_ids, int64_t n_items, int L, int64_t i_lo, int64_t i_hi);
 int dm_jtm_child_weights_cached(dm_handle_t h, const int32_t *item_node, int64_t i_lo, int64_t n_items, int old_level, int level,
                                 int hierarchical, int min_level, int use_mask, float *weights);
 /* One whole gap step of JTM.optimize (JTM.scala:36-72) over the cached catalogue on the device: the child weights of every item

@@ -20,8 +20,13 @@ class JTM(engine: HipEngine, itemIds: Array[Int], itemCodes: Array[Int], maxLeve
   def optimize(): Map[Int, Int] = {
     val n = itemIds.length
     val node = new Array[Int](n)
-    // itemSequenceMap goes to every worker's device once; the loop over the gap steps is one call
-    engines.foreach(e => Native.jtmCacheRows(e.handle, rowOff, rowItemIds, n.toLong, seqLen))
+    // every worker's device gets the bookkeeping of all items and the training rows of the item range it scores (JTM.scala:47-52);
+    // the loop over the gap steps is one call
+    engines.zipWithIndex.foreach { case (e, r) =>
+      val lo = new Array[Long](1); val hi = new Array[Long](1)
+      Native.jtmShardRange(n.toLong, r, engines.length, lo, hi)
+      Native.jtmCacheRowsRange(e.handle, rowOff, rowItemIds, n.toLong, seqLen, lo(0), hi(0))
+    }
     try {
       Native.jtmOptimizeAll(engines.map(_.handle), engines.length, itemCodes, n.toLong, maxLevel, gap, if (hierarchical) 1 else 0, minLevel,
         if (useMask) 1 else 0, node, null)

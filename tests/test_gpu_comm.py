@@ -229,6 +229,8 @@ def _jtm_worker(rank, world, port, q, items, depth=15, E=32):
     jt.comm = comm
     tim = {}
     proj = jt.optimize(as_array=True, timing=tim)
+    tim["sharding"]["rows_uploaded"] = tim["rows_uploaded"]
+    tim["sharding"]["rows_total"] = int(jt.row_off[-1])
     q.put((rank, proj, single, tim["sharding"]))
     comm.barrier()
     eng.attach_comm(None)
@@ -259,12 +261,15 @@ def test_jtm_sharded_optimize_equals_single_rank(world, items):
         assert st["nranks"] == world and st["transport"] == "host"
         # fewer parents than workers only at the root (1 parent) and — three workers — nowhere else: 4 >= 3
         assert st["steps_replicated_rebalance"] == 1 and st["steps_node_sharded"] == steps - 1
+        # a rank uploads the training rows of the items it scores only (dm_jtm_cache_rows_range): a share ~ 1 / W of the catalogue's
+        assert abs(st["rows_uploaded"] - st["rows_total"] / world) < 0.05 * st["rows_total"], st
         base, rem = divmod(items, world)
         assert st["items_scored"] == steps * (base + (1 if r < rem else 0))          # its contiguous item range, every step
         assert st["weight_bytes_gathered"] == (steps - 1) * items * 4 * 4 + items * (1 << (depth - (steps - 1) * gap)) * 4
         assert st["projection_bytes_gathered"] == (steps - 1) * items * 8               # (item, node) pairs of every item, every sharded step
         scored += st["items_rebalanced_sharded"]
     assert scored == (steps - 1) * items                                               # every item re-balanced by exactly one rank per step
+    assert sum(o[3]["rows_uploaded"] for o in out) == out[0][3]["rows_total"]            # ... and every training row uploaded by exactly one
 
 
 @pytest.mark.parametrize("world", [2, 3])

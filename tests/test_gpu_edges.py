@@ -604,6 +604,20 @@ def test_jtm_cached_entry_points_reject_bad_calls():
     assert lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, None, None) == -1            # no output
     secs = (C.c_double * 2)()
     eng._chk(lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, p(out), secs))                # and a good call works
+    # a handle that holds the rows of an item RANGE (a rank of a sharded run) scores that range and nothing else
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    assert lib.dm_jtm_shard_range(items, 1, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (100, 200)
+    assert lib.dm_jtm_shard_range(items, 3, 3, C.byref(lo), C.byref(hi)) == -1
+    full = np.empty((items, 4), np.float32)
+    eng._chk(lib.dm_jtm_child_weights_cached(eng._h, p(node), 0, items, 0, 2, 0, 0, 1, full.ctypes.data_as(N.f32p)))
+    lib.dm_jtm_shard_range(items, 1, 3, C.byref(lo), C.byref(hi))
+    eng._chk(lib.dm_jtm_cache_rows_range(eng._h, row_off.ctypes.data_as(N.i64p), p(rows), items, L, lo.value, hi.value))
+    part = np.empty((hi.value - lo.value, 4), np.float32)
+    eng._chk(lib.dm_jtm_child_weights_cached(eng._h, p(node[lo.value:hi.value].copy()), lo.value, hi.value - lo.value, 0, 2, 0, 0, 1, part.ctypes.data_as(N.f32p)))
+    assert np.array_equal(part, full[lo.value:hi.value])
+    assert lib.dm_jtm_child_weights_cached(eng._h, p(node), 0, items, 0, 2, 0, 0, 1, full.ctypes.data_as(N.f32p)) == -3       # DM_ERR_STATE
+    assert lib.dm_jtm_optimize_cached(eng._h, p(codes), items, depth, 2, 0, 0, 1, p(out), secs) == -3                          # one rank, a third of the rows
+    assert lib.dm_jtm_cache_rows_range(eng._h, row_off.ctypes.data_as(N.i64p), p(rows), items, L, 5, 4) == -1
     assert np.unique(out).size == items and out.min() >= (1 << depth) - 1 and secs[0] > 0
     eng._chk(lib.dm_jtm_cache_rows(eng._h, None, None, 0, L))
     eng.close()

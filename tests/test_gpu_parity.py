@@ -846,7 +846,8 @@ def test_otm_train_batch_long_history_f32(oracle):
     targets = [(first + rng.choice(1 << leaf_level, int(rng.integers(1, 4)), replace=False)).tolist() for _ in range(U)]
     odin = oracle.Din(w.copy(), E, L, NI)
     got = tr.beam_search_nodes(codes)
-    assert eng.last_beam_kernel() == "dm_beam_kernel<32, 4, true, 2>", eng.last_beam_kernel()      # (round 5: the fused two-key-tile kernel)
+    # round 5: the fused two-key-tile kernel (inside a training loop a small request takes its fp32-input arithmetic)
+    assert eng.last_beam_kernel() in ("dm_beam_kernel<32, 4, true, 2>", "dm_beam_kernel<32, 4, false, 2>"), eng.last_beam_kernel()
     for lv in range(len(got)):
         for u in range(U):
             nodes = np.array([n for n, _ in got[lv][u]], np.int32)

@@ -57,7 +57,7 @@ HANDWRITTEN = {"dm_dr_load_model"}          # struct with pointer arrays: writte
 # entry points that neither wait on peers / the network nor run a long device job: the only ones allowed a Critical region
 # (not dm_create — HIP runtime and device initialisation can take seconds — and not dm_memcpy_h2d / _d2h: arbitrarily large
 # synchronous copies; both would hold the GC locker for their whole duration)
-CRITICAL_OK = {"dm_level_start", "dm_tdm_id_to_code", "dm_kernel_timing_get",
+CRITICAL_OK = {"dm_level_start", "dm_jtm_shard_range", "dm_tdm_id_to_code", "dm_kernel_timing_get",
                "dm_kernel_timing_get_kind", "dm_get_scorer_mode", "dm_comm_rank", "dm_device_count", "dm_last_scored_rows",
                "dm_train_last_loss", "dm_train_sync_stats", "dm_jtm_last_step_seconds", "dm_adam_last_step_rows", "dm_comm_unique_id", "dm_dev_alloc"}
 JTYPE = {"jint": "Int", "jlong": "Long", "jfloat": "Float", "jdouble": "Double", "jbyte": "Byte"}
@@ -80,6 +80,8 @@ EXTENTS = {
     "dm_tdm_bruteforce_topk": {"seq_item_ids": "U * L", "out_item_ids": "U * topk", "out_scores": "U * topk", "out_counts": "U"},
     "dm_jtm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
     "dm_jtm_cache_rows": {"row_off": "n_items + 1"},
+    "dm_jtm_cache_rows_range": {"row_off": "n_items + 1"},
+    "dm_jtm_shard_range": {"i_lo": "1", "i_hi": "1"},
     "dm_jtm_child_weights_cached": {"item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
     "dm_jtm_step_cached": {"item_node": "n_items", "old_node": "n_items", "out_node": "n_items"},
     "dm_jtm_optimize_cached": {"item_code": "n_items", "out_proj": "n_items"},
