@@ -3,6 +3,7 @@
     python -m dismember_amd.tasks TDMInitializeTree --tdmConfFile configs/c1_tdm_movielens.conf
     python -m dismember_amd.tasks TDMTrainDeepModel --tdmConfFile configs/c1_tdm_movielens.conf [--quiet]
     python -m dismember_amd.tasks JTMTreeLearning   --jtmConfFile <file>
+    python -m dismember_amd.tasks OTMTrainDeepModel --otmConfFile <file>     (then OTMConstructTree on the same file)
 
 Each function is the body of the reference's `CommandApp` of the same name (examples/src/main/scala/com/mass/retrieval/):
 the conf file is read by dismember_amd.conf (same keys, same defaults, same "failed to find <key>" stop), the steps are the
@@ -14,6 +15,8 @@ is `dm_save_model`'s flat checkpoint), HDFS paths, the DeepFM graph and the k-me
   tdm_train_deep_model  tdm/TDMTrainDeepModel.scala:20-83  -> LocalDataSet + LocalOptimizer.optimize (tdm/.../optim/LocalOptimizer.scala:58-126),
                         TDM.saveModel (:32-41), package.recommend (tdm/package.scala:114-124)
   jtm_tree_learning     jtm/JTMTreeLearning.scala:17-48    -> JTM.optimize (jtm/.../optim/JTM.scala:26-73), TreeUtil.writeTree
+  otm_train_deep_model  otm/OTMTrainDeepModel.scala:20-75  -> LocalDataSet (dismember_amd/otm_data.py), LocalOptimizer.optimize, OTM.saveModel
+  otm_construct_tree    otm/OTMConstructTree.scala:17-45   -> TreeConstruction.run, Serialization.saveMapping
 """
 import os
 import sys
@@ -194,10 +197,138 @@ def jtm_tree_learning(conf_path, quiet=True, engine=None):
     return dict(projection=proj, seconds=dt, params=p, engine=eng)
 
 
+def _otm_sample(path):
+    """LocalDataSet.readFile (otm/.../dataset/LocalDataSet.scala:152-161) — category kept as read (the `category` leaf order compares it)"""
+    if path.endswith(".npz"):
+        return _read_interactions(path)
+    users, items, cats, times = [], [], [], []
+    with open(path) as f:
+        for line in f:
+            arr = line.strip().split(",")
+            if len(arr) != 5 or not tree_io._is_creatable(arr[0]):
+                continue
+            users.append(int(arr[0])); items.append(int(arr[1])); times.append(int(arr[3])); cats.append(arr[4])
+    return dict(user=users, item=items, category=cats, timestamp=times)
+
+
+def otm_train_deep_model(conf_path, quiet=True, engine=None, max_iterations=None, time_recommend=True):
+    """OTMTrainDeepModel (examples/.../otm/OTMTrainDeepModel.scala:20-75): data set + mapping (LocalDataSet), DIN[Double] over the
+    complete tree of upperLog2(#items) levels, LocalOptimizer.optimize (otm/.../optim/LocalOptimizer.scala:55-110: per epoch a shuffle,
+    batches of train_batch_size users, ONE library call per batch = pseudo targets + beam nodes + a gradient step per level), the
+    evaluator at the progress interval and at the end of every epoch, OTM.saveModel (model checkpoint + `item node` mapping lines).
+    -> dict(epoch_losses {"epoch k": per-level loss lists}, eval [(epoch, iter, loss, OtmEvalResult)], recommendation, mapping, params)"""
+    from . import otm_data as od
+    from .engine import Engine
+    from .facade import OTM
+    from .otm_train import OTMTrainer
+    p = C.task_params("OTMTrainDeepModel", conf_path)
+    if p["deep_model"] != "din":
+        raise ValueError("DeepModel name should either be DeepFM or DIN (DeepFM is out of scope of this build)")
+    if p["train_batch_size"] < p["thread_number"]:
+        raise ValueError("requirement failed: train_batch_size >= thread_number")
+    if not quiet:
+        print("\n".join("%s: %s" % kv for kv in sorted(p.items())))
+    L, E, beam = p["seq_len"], p["embed_size"], p["beam_size"]
+    sample = _otm_sample(p["data_path"])
+    rng = np.random.default_rng(p["seed"])
+    if p["initialize_mapping"]:
+        mapping = od.initialize_mapping(sample, p["leaf_init_mode"], rng)
+    else:
+        mapping = od.load_mapping(p["mapping_path"])
+    consumed, train, evals = od.generate_samples(sample, mapping, L, p["min_seq_len"], p["split_ratio"], p["label_num"])
+    leaf_level = od.upper_log2(len(mapping))
+    ni = (1 << (leaf_level + 1)) - 1                                   # dataset.numTreeNode
+    eng = engine or Engine(0)
+    eng.load_weights_din(_din_init(E, ni, p["seed"], dtype=np.float64), E, ni)
+    tr = OTMTrainer(eng, leaf_level=leaf_level, beam=beam, seq_len=L, lr=p["learning_rate"])
+    allowed = ev.all_nodes(list(mapping.values()))
+    tseq = np.array([t[0] for t in train], np.int32)
+    ttgt = [t[1] for t in train]
+    eseq = np.array([e[0] for e in evals], np.int32).reshape(-1, L)
+    elab = [e[1] for e in evals]
+    euser = np.array([e[2] for e in evals], np.int64)
+    bs = p["train_batch_size"]
+    n_batch = int(np.ceil(len(train) / float(bs)))
+    interval = p["show_progress_interval"]
+    epoch_losses, evals_out = {}, []
+    done = 0
+    for epoch in range(1, p["epoch_num"] + 1):
+        order = rng.permutation(len(train))
+        per_batch = []
+        t_epoch, count = 0.0, 0
+        for it in range(1, n_batch + 1):
+            idx = order[(it - 1) * bs:it * bs]
+            t0 = time.perf_counter()
+            losses = tr.train_batch(tseq[idx], [ttgt[i] for i in idx], p["target_mode"])
+            dt = time.perf_counter() - t0
+            t_epoch += dt; count += len(idx)
+            per_batch.append(losses)
+            done += 1
+            if it == n_batch or (interval > 0 and it % interval == 0):
+                if len(evals):
+                    loss, res = ev.evaluate_otm(eng, eseq, elab, euser, consumed, allowed, leaf_level, p["topk_number"], p["eval_batch_size"], beam)
+                else:
+                    loss, res = float("nan"), ev.OtmEvalResult()
+                evals_out.append((epoch, it, loss, res))
+                if not quiet:
+                    print("Epoch %d Train %d/%d Iteration %d/%d Wall clock %.4fs Train time %.4fs Train loss %.4f\n\teval loss: %.4f, %s"
+                          % (epoch, count, len(train), it, n_batch, t_epoch, dt, losses[-1], loss, res))
+            if max_iterations is not None and done >= max_iterations:
+                break
+        epoch_losses["epoch %d" % epoch] = [list(x) for x in zip(*per_batch)]         # epochLoss.toList.transpose: per level, over the batches
+        if max_iterations is not None and done >= max_iterations:
+            break
+    _mkdir_for(p["model_path"], p["mapping_path"])
+    eng.save_model(p["model_path"])                                    # OTM.saveModel (OTM.scala:31-40)
+    od.save_mapping(p["mapping_path"], mapping)
+    otm = OTM(eng, mapping, p["deep_model"])
+    query = [0, 0, 2126, 204, 3257, 3439, 996, 1681, 3438, 1882]
+    query = query[-L:] if L <= 10 else [0] * (L - 10) + query
+    out = dict(epoch_losses=epoch_losses, eval=evals_out, mapping=mapping, params=p, engine=eng, n_train=len(train), n_eval=len(evals))
+    out["recommendation"] = otm.recommend(query, 3, 20)
+    if not quiet:
+        print("Recommendation result: %s" % (out["recommendation"],))
+    if time_recommend:                                                 # otm/package.scala:100-105
+        for _ in range(10):
+            otm.recommend(query, 10, 20)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            otm.recommend(query, 10, 20)
+        out["recommend_ms"] = (time.perf_counter() - t0) * 10
+        if not quiet:
+            print("Average recommend time: %.4fms" % out["recommend_ms"])
+    return out
+
+
+def otm_construct_tree(conf_path, quiet=True, engine=None):
+    """OTMConstructTree (examples/.../otm/OTMConstructTree.scala:17-45): the trained model + the mapping file -> TreeConstruction.run
+    (otm/.../tree/TreeConstruction.scala:44-101) over the items' training histories -> the new `item node` mapping written back."""
+    from . import otm_data as od
+    from .engine import Engine
+    from .otm_tree import TreeConstruction
+    p = C.task_params("OTMConstructTree", conf_path)
+    if not quiet:
+        print("\n".join("%s: %s" % kv for kv in sorted(p.items())))
+    eng = engine or Engine(0)
+    eng.load_model(p["model_path"])
+    mapping = od.load_mapping(p["mapping_path"])
+    sample = _otm_sample(p["data_path"])
+    seqs = od.item_sequences(sample, mapping, p["label_num"], p["min_seq_len"], p["seq_len"], p["split_ratio"])
+    tc = TreeConstruction(eng, mapping, seqs, gap=p["gap"], seq_len=p["seq_len"], use_mask=p["use_mask"])
+    t0 = time.perf_counter()
+    result = tc.run()
+    dt = time.perf_counter() - t0
+    if not quiet:
+        print("OTM tree construction time: %.4fs" % dt)
+    od.save_mapping(p["mapping_path"], result)
+    return dict(mapping=result, old_mapping=mapping, seconds=dt, params=p, engine=eng)
+
+
 TASK_FUNCS = {
     "TDMInitializeTree": tdm_initialize_tree, "JTMInitializeTree": tdm_initialize_tree,
     "TDMTrainDeepModel": tdm_train_deep_model, "JTMTrainDeepModel": tdm_train_deep_model,
     "JTMTreeLearning": jtm_tree_learning,
+    "OTMTrainDeepModel": otm_train_deep_model, "OTMConstructTree": otm_construct_tree,
 }
 
 
