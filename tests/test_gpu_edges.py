@@ -125,12 +125,13 @@ def test_history_lengths_17_to_32_tdm(oracle, monkeypatch, E, L, route):
 
 
 @pytest.mark.parametrize("dtype,E,L,beam,route", [("f64", 128, 17, 33, "pipeline"), ("f64", 64, 32, 100, "pipeline"),
+                                                  ("f64", 128, 17, 33, "fused"), ("f64", 64, 32, 100, "fused"), ("f64", 32, 24, 7, "fused"), ("f64", 128, 29, 300, "fused"),
                                                   ("f32", 128, 24, 33, "fused"), ("f32", 128, 32, 7, "fused"), ("f32", 32, 19, 100, "fused"),
                                                   ("f32", 128, 24, 33, "pipeline"), ("f32", 128, 32, 7, "pipeline")])
 def test_history_lengths_17_to_32_otm(oracle, monkeypatch, dtype, E, L, beam, route):
     """OTM searches with 17..32 history positions: f32 models run the fused LDS-fed kernel's two-key-tile instance
-    (csrc/beam_kernel.hip.inc), fp64 models (and DM_LONG_PIPELINE=1) the per-level pipeline in the model's own type
-    (csrc/otm64.hip.inc): buildBeamNodes (otm/.../model/CandidateSearcher.scala:109-122) replayed exactly on the device's scores;
+    (csrc/beam_kernel.hip.inc), fp64 models the fused fp64 kernel's (dm_beam64_kernel<E, 4, 2>, csrc/beam_kernel_f64.hip.inc);
+    DM_LONG_PIPELINE=1 keeps the per-level pipeline in the model's own type (csrc/otm64.hip.inc): buildBeamNodes (otm/.../model/CandidateSearcher.scala:109-122) replayed exactly on the device's scores;
     fp64 models: node lists equal to the fp64 oracle's and scores within 1e-10 / 1e-9; f32 models: scores within the fp32 tolerance."""
     from dismember_amd import Engine
     from test_gpu_precision import _otm_replay
@@ -159,6 +160,8 @@ def test_history_lengths_17_to_32_otm(oracle, monkeypatch, dtype, E, L, beam, ro
         tol = (ATOL, RTOL)
     if route == "pipeline":
         assert "pipeline" in eng.last_beam_kernel()
+    elif dtype == "f64":
+        assert eng.last_beam_kernel() == "dm_beam64_kernel<%d, 4, 2>" % E, eng.last_beam_kernel()
     else:
         assert eng.last_beam_kernel() == "dm_beam_kernel<%d, 4, true, 2>" % E, eng.last_beam_kernel()
     _otm_replay(oracle, tc, ts, tn, beam, start_level, leaf_level, ids)

@@ -751,7 +751,7 @@ def test_otm_train_batch_long_history(oracle):
     targets = [(first + rng.choice(1 << leaf_level, int(rng.integers(1, 4)), replace=False)).tolist() for _ in range(U)]
     odin = oracle.Din(w.copy(), E, L, NI)
     got = tr.beam_search_nodes(codes)
-    assert "pipeline" in eng.last_beam_kernel()
+    assert eng.last_beam_kernel() == "dm_beam64_kernel<32, 4, 2>", eng.last_beam_kernel()      # (round 5: the fused kernel's two-key-tile instance)
     ref = oo.beam_search_nodes(odin, codes, L, tr.start_level, leaf_level, beam)
     for lv in range(len(ref)):
         for u in range(U):
