@@ -7,6 +7,7 @@
 #   (3) the same with --scorer f32                                                                   -> prof_r05_f32
 #   (4) kernel trace + PMC passes of the fp64 OTM beam kernel at depth 24 (tools/otm_f64_bench.py)   -> prof_r05_otm64_d24
 #   (5) kernel trace + PMC passes of the Deep-Retrieval search, fp64 and f32 (tools/dr_bench.py)     -> prof_r05_dr_f64 / prof_r05_dr_f32
+#   (7) `longhist` (not part of `all`): tools/long_history_bench.py 32768 (the two-key-tile kernels)   -> prof_r05_longhist
 #   (6) `otmtrain` (not part of `all`): the fp64 OTM training iteration at 8 192 users                 -> prof_r05_otmtrain
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -39,4 +40,5 @@ if [ "$WHAT" = diverse ]; then       # the headline search on beams that diverge
   pmc_set gpurun_out/prof_r05_diverse python tools/diverse_bench.py 131072 4 s1.7e32
   pmc_set gpurun_out/prof_r05_diverse_head python tools/diverse_bench.py 131072 4 head
 fi
+if [ "$WHAT" = longhist ]; then pmc_set gpurun_out/prof_r05_longhist python tools/long_history_bench.py 32768; fi     # histories of 17 / 24 / 32 positions: dm_beam_kernel<128, 4, true, 2> and dm_beam64_kernel<128, 4, 2>
 ls gpurun_out/prof_r05*/ | head -40
