@@ -22,7 +22,7 @@ pmc_set() {   # $1 = out dir, rest = command
   timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o p -- "$@" > $OUT/bench_pmc4.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_lds -o p -- "$@" > $OUT/bench_pmc5.log 2>&1
 }
-HEAD="--steps 4 --warmup 1 --cpu-users 0 --recall-users 0 --small 0 --train 0 --dr 0 --other-scorer 0 --otm64 0"
+HEAD="--steps 4 --warmup 1 --cpu-users 0 --recall-users 0 --small 0 --train 0 --dr 0 --other-scorer 0 --otm64 0 --diverse 0 --long-history 0 --host-buffer-steps 0 --jtm-full 0"
 if [ "$WHAT" = all ] || [ "$WHAT" = full ]; then
   mkdir -p gpurun_out/prof_r05_all
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r05_all/trace -o t -- python bench.py --steps 6 --warmup 1 --cpu-users 0 > gpurun_out/prof_r05_all/bench_trace.log 2>&1
