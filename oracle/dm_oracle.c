@@ -17,6 +17,11 @@
  *     tests/test_oracle.py::test_trained_weights_pin_layout, tools/trained_weights_pin_probe.py): the concat order
  *     [item; att] of linear1's input, the positions of l1.b / l2.W / l2.b in the compact vector and the sign of l2.W —
  *     NOT the orientation of l1.W / att.W (the bundled models are not converged: +-0.01 BCE either way).
+ *   - the OTM path end to end on the reference's artefacts (round 5, tests/test_oracle.py::
+ *     test_otm_trained_model_pins_mapping_search_and_evaluator): the bundled trained DIN[Double] with the bundled item -> node
+ *     mapping explains the bundled interactions (recall@10 0.0144, eval loss 3.02) against 0.0008 .. 0.0038 / 3.65 .. 3.86 when
+ *     the same nodes are dealt to the items at random — the id space of the mapping file, the leaf range, the fp64 forward's
+ *     layout, the beam search and the evaluator's consumed / allNodes filter are all on that path.
  *
  * Citation prefixes:  T/ = tdm/src/main/scala/com/mass/tdm/
  *                     O/ = otm/src/main/scala/com/mass/otm/

@@ -166,3 +166,29 @@ def test_evaluate_dr_vs_oracle():
     assert (res.precision, res.recall, res.ndcg) == pytest.approx((op, or_, og), rel=1e-12, abs=0)
     assert res.recall > 0
     eng.close()
+
+
+@pytest.mark.gpu
+def test_evaluate_otm_on_the_reference_model_and_mapping(oracle, fixture_w64):
+    """The device evaluator on the reference's own artefacts: bundled trained DIN[Double], bundled item -> node mapping, the bundled
+    interactions split by LocalDataSet.generateSamples — per-sample lists equal the fp64 oracle's, so the metrics are equal."""
+    from dismember_amd import Engine, otm_data as od, tasks
+    m = np.load(os.path.join(os.path.dirname(__file__), "golden", "otm_mapping.npy"))
+    mapping = {int(a): int(b) for a, b in m}
+    s = tasks._otm_sample(os.path.join(os.path.dirname(__file__), "golden", "example_data.npz"))
+    E, L, leaf_level, beam, topk = 16, 10, 12, 20, 10
+    NI = (1 << (leaf_level + 1)) - 1
+    consumed, _, evals = od.generate_samples(s, mapping, L, 2, 0.8, 5)
+    evals = evals[:600]
+    seqs = np.array([e[0] for e in evals], np.int32)
+    labels, users = [e[1] for e in evals], np.array([e[2] for e in evals])
+    allowed = ev.all_nodes(list(mapping.values()))
+    eng = Engine(0)
+    eng.load_weights_din(fixture_w64, E, NI)
+    loss, res = ev.evaluate_otm(eng, seqs, labels, users, consumed, allowed, leaf_level, topk, 8192, beam)
+    odin = oracle.Din(fixture_w64, E, L, NI)
+    oloss, ores = eo.evaluate_otm(lambda sq: oracle.otm_beam_search(odin, np.asarray(sq, np.int32), leaf_level, beam), seqs, labels, users, consumed,
+                                  allowed, topk, 8192, beam)
+    assert (res.precision, res.recall, res.ndcg) == pytest.approx(ores, rel=1e-12, abs=0) and res.recall > 0.005
+    assert loss == pytest.approx(oloss, rel=1e-8)
+    eng.close()

@@ -281,3 +281,39 @@ def test_trained_weights_pin_layout(oracle, fixture_tree, fixture_w32):
         # recorded, not asserted (not separable): the orientation of l1.W, att.W and of the table
         for k in ("l1.W read as [in][out]", "att.W transposed", "emb read as [E][index]"):
             assert abs(res[k][0] - loaded) < 0.05
+
+
+def test_otm_trained_model_pins_mapping_search_and_evaluator(oracle, fixture_w64):
+    """Reference artefacts on the OTM path (round 5): the bundled trained DIN[Double] (data/otm/example_model.bin -> din_f64.npy) was trained
+    on the tree its bundled mapping (data/otm/example_mapping.txt -> otm_mapping.npy) places the items in.  Run through the restated
+    pipeline — LocalDataSet.generateSamples (dismember_amd/otm_data.py), CandidateSearcher.beamSearch + DIN forward (oracle), the OTM
+    Evaluator (oracle/eval_oracle.py) — the model must explain the bundled interactions far better with ITS mapping than with the same
+    nodes dealt to the items at random: a wrong id space (items vs nodes), a wrong leaf range, a transposed weight layout or a broken
+    consumed / allNodes filter would all collapse the gap.  (The bundled model is lightly trained: absolute recall is small.)"""
+    from dismember_amd import otm_data as od, tasks
+    from oracle import eval_oracle as eo
+    m = np.load(os.path.join(GOLDEN, "otm_mapping.npy"))
+    mapping = {int(a): int(b) for a, b in m}
+    s = tasks._otm_sample(os.path.join(GOLDEN, "example_data.npz"))
+    E, L, beam, topk = 16, 10, 20, 10
+    leaf_level = od.upper_log2(len(mapping))
+    NI = (1 << (leaf_level + 1)) - 1
+    assert leaf_level == 12 and fixture_w64.size == NI * E + 3 * E * E + 2 * E + 1
+    nodes = np.array(sorted(mapping.values()))
+    assert nodes.min() >= (1 << leaf_level) - 1 and nodes.max() <= NI - 1 and np.unique(nodes).size == len(mapping)      # TreeConstructionSpec.scala:38-48
+    din = oracle.Din(fixture_w64, E, L, NI)
+
+    def run(mp):
+        consumed, _, evals = od.generate_samples(s, mp, L, 2, 0.8, 5)
+        allowed = eo.all_nodes(list(mp.values()))
+        loss, (p, r, n) = eo.evaluate_otm(lambda sq: oracle.otm_beam_search(din, np.asarray(sq, np.int32), leaf_level, beam),
+                                          [e[0] for e in evals], [e[1] for e in evals], [e[2] for e in evals], consumed, allowed, topk, 8192, beam)
+        return loss, p, r, n
+
+    ref = run(mapping)
+    items, vals = list(mapping), list(mapping.values())
+    for seed in (0, 1, 2):          # (measured over seeds 0 .. 4: recall 0.0144 against 0.0008 .. 0.0038, loss 3.02 against 3.65 .. 3.86)
+        perm = np.random.default_rng(seed).permutation(len(vals))
+        shuf = run({it: vals[j] for it, j in zip(items, perm)})
+        assert ref[2] > 3 * shuf[2] and ref[1] > 2 * shuf[1] and ref[3] > 1.5 * shuf[3], (ref, shuf)    # recall, precision, ndcg @ 10
+        assert ref[0] < shuf[0] - 0.4, (ref, shuf)                                                      # eval loss (BCE sum per sample)
