@@ -149,7 +149,10 @@ typedef struct {
 /* seq_item_ids [U*L] raw item ids (0 = padding).  consumed_off [U+1] / consumed_ids: CSR of
  * already-consumed item ids per user, or NULL/NULL.  Outputs: out_item_ids/out_scores [U*topk]
  * (scores are LOGITS; the facade applies sigmoid in double like T/model/TDM.scala:56-58),
- * out_counts [U] (<= topk). */
+ * out_counts [U] (<= topk).
+ * L = seq_len, 1 .. 32 (the reference's Attention takes any length, S/nn/Attention.scala:34-53; its configs use 10): up to 16 positions run on
+ * the one-wave kernel, 17 .. 32 on the fused LDS-fed kernel's two-key-tile instance (f32 models; fp64 OTM searches on the fp64 kernel's);
+ * L > 32 is DM_ERR_INVALID, never a truncated history. */
 int dm_tdm_beam_search(dm_handle_t h, const int32_t *seq_item_ids, int64_t U, int L, const dm_tdm_search_opts *opts,
                        const int64_t *consumed_off, const int32_t *consumed_ids, int32_t *out_item_ids,
                        float *out_scores, int32_t *out_counts);
