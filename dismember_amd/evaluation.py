@@ -227,6 +227,11 @@ def evaluate_dr(engine, sequences, labels, users, user_consumed, topk, beam_size
         p = r = g = 0.0
         for i in range(n):
             rec = [int(v) for v in ids[i, :cnt[i]] if int(v) not in cons[i]][:topk]
+            if len(rec) < topk and cnt[i] == k and k < topk + len(cons[i]):
+                # the device list was cut at dm_dr_recommend's 2 048 items before `topk` unconsumed ones were seen: say so instead of
+                # silently scoring a shorter list than the reference would
+                raise ValueError("evaluate_dr: user %d has %d consumed items; topk + consumed exceeds dm_dr_recommend's 2048-item limit"
+                                 % (int(users[off + i]), len(cons[i])))
             m = compute_metrics(np.asarray(rec, np.int64), list(labels[off + i]))
             p += m[0]; r += m[1]; g += m[2]
         ll, rl = loss_fn(off, n) if loss_fn else ([0.0] * num_layer, 0.0)

@@ -78,19 +78,19 @@ EXTENTS = {
     "dm_otm_beam_search_trace": dict(_OTM_OUT, trace_counts="U * max_levels"),
     "dm_otm_beam_search_trace_f64": dict(_OTM_OUT, trace_counts="U * max_levels"),
     "dm_tdm_bruteforce_topk": {"seq_item_ids": "U * L", "out_item_ids": "U * topk", "out_scores": "U * topk", "out_counts": "U"},
-    "dm_jtm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
+    "dm_jtm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))"},
     "dm_jtm_cache_rows": {"row_off": "n_items + 1"},
     "dm_jtm_cache_rows_range": {"row_off": "n_items + 1"},
     "dm_jtm_shard_range": {"i_lo": "1", "i_hi": "1"},
-    "dm_jtm_child_weights_cached": {"item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
+    "dm_jtm_child_weights_cached": {"item_node": "n_items", "weights": "n_items * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))"},
     "dm_jtm_step_cached": {"item_node": "n_items", "old_node": "n_items", "out_node": "n_items"},
     "dm_jtm_optimize_cached": {"item_code": "n_items", "out_proj": "n_items"},
     "dm_jtm_optimize_all": {"hs": "n", "item_code": "n_items", "out_proj": "n_items"},
-    "dm_jtm_rebalance": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "out_node": "n"},
-    "dm_jtm_rebalance_all": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "item_node": "n", "out_node": "n"},
-    "dm_otm_rebalance_all": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "item_node": "n", "out_node": "n"},
-    "dm_otm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level - old_level))"},
-    "dm_otm_rebalance": {"weights": "n * ((jlong)1 << (level - old_level))", "old_node": "n", "out_node": "n"},
+    "dm_jtm_rebalance": {"weights": "n * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))", "old_node": "n", "out_node": "n"},
+    "dm_jtm_rebalance_all": {"weights": "n * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))", "old_node": "n", "item_node": "n", "out_node": "n"},
+    "dm_otm_rebalance_all": {"weights": "n * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))", "old_node": "n", "item_node": "n", "out_node": "n"},
+    "dm_otm_child_weights": {"row_off": "n_items + 1", "item_node": "n_items", "weights": "n_items * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))"},
+    "dm_otm_rebalance": {"weights": "n * ((jlong)1 << (level > old_level && level - old_level < 32 ? level - old_level : 0))", "old_node": "n", "out_node": "n"},
     "dm_train_forward_backward": {"codes": "B", "seqs": "B * L", "pad_flat_idx": "n_pad", "labels": "B", "loss": "1"},
     "dm_comm_create_all": {"devices": "n", "out": "n"},
     "dm_comm_allreduce_f64": {"vals": "n"},
