@@ -939,6 +939,22 @@ def main():
                                   "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak_mm, "kernel_ms_avg": gemm_ms, "traffic": None,
                                   "flops_per_user": 2 * Dd * Kd * Ld * Ed,
                                   "note": "the dominant kernel of the search (%.0f %% of the kernel time)" % (100.0 * gemm_ms / max(kms_b / nsd, 1e-9))}
+                # operand delivery of the 128 x 128-tiled GEMM: every row tile's A operand (gathered history rows) is read once per column tile
+                # and every column tile's B operand once per row tile, through the L1 / L2 fabric (round 5: what bounds the split GEMM)
+                tiles_m, tiles_n = -(-Ud // 128), -(-(Dd * Kd) // 128)
+                op_bytes = float(Ud) * Ld * Ed * esz_ * tiles_n + float(Dd * Kd) * Ld * Ed * esz_ * tiles_m
+                rl["roofline"]["operand_bytes_per_launch"] = op_bytes
+                rl["roofline"]["operand_delivery_TBps"] = op_bytes / (gemm_ms * 1e-3) / 1e12
+                rl["roofline"]["operand_delivery_note"] = ("128 x 128 tiles: A re-read per column tile, B per row tile; the L1 / L2 fabric delivered 8 - 9.5 TB/s to the gather "
+                                                           "micro-benchmark (tools/gather_microbench.hip, DESIGN.md §4): the split GEMM sits at that ceiling, the fp64 GEMM at its pipe")
+                try:          # HBM bytes of the profiled GEMM (rocprofv3 PMC passes of tools/dr_bench.py, profiles/r05_dr_*), attached when the kernel and its duration match
+                    prof_ = json.load(open(os.path.join(ROOT, "profiles", "r05_dr_%s_summary.json" % tag)))
+                    pk_ = prof_["kernel_trace"]
+                    if rl["roofline"]["kernel"].split("<")[0] in pk_["kernel"] and abs(pk_["avg_ns"] / 1e6 - gemm_ms) <= 0.05 * gemm_ms and Ud == 16384:
+                        rl["roofline"]["traffic"] = prof_["hbm_traffic_per_launch_bytes"]["total_corrected"]
+                        rl["roofline"]["traffic_source"] = "profiles/r05_dr_%s_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % tag
+                except Exception:
+                    pass
             if st_ms > 0:
                 rl["roofline_statistics_kernels"] = {"bound": "l2", "kernel": "drs_stats_kernel<%s, 1> + <%s, 2>" % (("double",) * 2 if tag == "f64" else ("float",) * 2),
                                                      "achieved": st_bytes / (st_ms * 1e-3) / 1e9, "peak": 34500.0, "unit": "GB/s",
