@@ -260,3 +260,38 @@ def test_sliced_pipeline_equals_one_kernel_on_a_batch(dtype, dr_search_path):
         np.testing.assert_allclose(pra[same], prb[same], rtol=2e-5, atol=0)
     assert np.array_equal(pa[1], pa[2]) and np.array_equal(pra[1], pra[2])
     assert (np.diff(pra, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("K,L,E,U", [(100, 13, 64, 600), (86, 3, 128, 1061), (1000, 10, 128, 12288 + 37)])
+def test_presplit_history_gemm_is_bit_identical_to_the_128_tile_kernel(K, L, E, U, dr_search_path):
+    """Batches of 12 288 users and more run the history GEMM on 256 x 256 tiles over operands split into fp16 hi/lo records once at model
+    load and copied global -> LDS directly (dr_gemm_split_x_kernel).  Same split arithmetic and the same order of MFMAs per accumulator
+    as the 128 x 128 kernel, so the two must agree in every bit: paths, probabilities and counts of a whole search, on shapes that leave
+    ragged row and column tiles, idle XCD slots, a history longer than the 12 cached ids per row, and padding ids."""
+    if dr_search_path == "sliced" and U > 2000:
+        pytest.skip("the batch takes the sliced pipeline by its size; the forced variant adds nothing")
+    from dismember_amd import Engine
+    rng = np.random.default_rng(33)
+    D, n, beam = 3, 5000, 10
+    w = synth.make_dr_model(n, K, D, L, E, rng, scale=0.08)
+    seqs = histories(rng, U, L, n)
+    out = {}
+    for x in ("0", "1"):
+        os.environ["DM_DR_GEMM_X"] = x
+        os.environ["DM_DR_GEMM_X_MIN_ROWS"] = "1" if U < 12288 else "12288"
+        try:
+            eng = Engine(0)
+            eng.dr_load_model(w, E, L, K, D, n, dtype=np.float32)
+            out[x] = eng.dr_beam_search(seqs, beam)
+            eng.set_scorer_mode("f32")
+            ref = eng.dr_beam_search(seqs[:64], beam)
+            eng.close()
+        finally:
+            os.environ.pop("DM_DR_GEMM_X", None)
+            os.environ.pop("DM_DR_GEMM_X_MIN_ROWS", None)
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+    assert (out["1"][2] > 0).all()
+    same = (out["1"][0][:64] == ref[0]).all(axis=(1, 2))          # and close to the fp32-input GEMM, like the 128 x 128 kernel
+    assert same.mean() > 0.9
+    np.testing.assert_allclose(out["1"][1][:64][same], ref[1][same], rtol=2e-5, atol=0)
