@@ -952,7 +952,9 @@ def main():
                                                             "(tools/dr_gemm_probe.hip): matrix work alone 0.23 ms, loads alone 0.19 ms (gather latency, one stage in flight), together 0.33 ms")
                                                            if x_tiles else
                                                            ("128 x 128 tiles: A re-read per column tile, B per row tile; knock-out builds (tools/dr_gemm_probe.hip) put the matrix work "
-                                                            "alone at 0.23 ms, the staging alone at 0.31 ms, barely overlapping (VALU split instructions take matrix-pipe issue cycles)"))
+                                                            "alone at 0.23 ms, the staging alone at 0.31 ms, barely overlapping (VALU split instructions take matrix-pipe issue cycles)")
+                                                           if tag == "f32" else
+                                                           "128 x 128 tiles, fp64 MFMA: the matrix pipe bounds this kernel (DESIGN.md §3: 0.92 of what its instruction mix delivers)")
                 try:          # HBM bytes of the profiled GEMM (rocprofv3 PMC passes of tools/dr_bench.py, profiles/r05_dr_*), attached when the kernel and its duration match
                     prof_ = json.load(open(os.path.join(ROOT, "profiles", "r05_dr_%s_summary.json" % tag)))
                     pk_ = prof_["kernel_trace"]

@@ -267,7 +267,7 @@ def test_presplit_history_gemm_is_bit_identical_to_the_128_tile_kernel(K, L, E, 
     """Batches of 12 288 users and more run the history GEMM on 256 x 256 tiles over operands split into fp16 hi/lo records once at model
     load and copied global -> LDS directly (dr_gemm_split_x_kernel).  Same split arithmetic and the same order of MFMAs per accumulator
     as the 128 x 128 kernel, so the two must agree in every bit: paths, probabilities and counts of a whole search, on shapes that leave
-    ragged row and column tiles, idle XCD slots, a history longer than the 12 cached ids per row, and padding ids."""
+    ragged row and column tiles, idle XCD slots, E = 64 (two stages per history position) and padding ids."""
     if dr_search_path == "sliced" and U > 2000:
         pytest.skip("the batch takes the sliced pipeline by its size; the forced variant adds nothing")
     from dismember_amd import Engine

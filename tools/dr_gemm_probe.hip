@@ -11,9 +11,9 @@ int main(int argc, char **argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 16384, items = 2000000;
   const int N = 3000, E = 128, L = 10, Kd = L * E;
   float *emb, *C, *bias, *zero; _Float16 *Bp; int32_t *gidx;
-  CK(hipMalloc(&emb, items * E * 4)); CK(hipMalloc(&C, M * N * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&zero, 1024));
+  CK(hipMalloc(&emb, items * E * 4)); CK(hipMalloc(&C, M * N * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&zero, 4096));
   CK(hipMalloc(&Bp, (size_t)2 * N * Kd * 2 + 4096)); CK(hipMalloc(&gidx, M * L * 4));
-  CK(hipMemset(emb, 0x3c, items * E * 4)); CK(hipMemset(Bp, 0x3c, (size_t)2 * N * Kd * 2)); CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(zero, 0, 1024));
+  CK(hipMemset(emb, 0x3c, items * E * 4)); CK(hipMemset(Bp, 0x3c, (size_t)2 * N * Kd * 2)); CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(zero, 0, 4096));
   std::vector<int32_t> g(M * L);
   unsigned long long x = 88172645463325252ull;
   for (auto &v : g) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (x % 100) < 15 ? -1 : (int32_t)(x % items); }
