@@ -316,6 +316,21 @@ def stage(msg):
         sys.stderr.write("[bench rank %s %.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg)); sys.stderr.flush()
 
 
+def sustained_mfma_tflops():
+    """Mean sustained rates of tools/mfma_power_microbench.hip from its committed log: {'f16_quiet', 'f16_random', 'f64_quiet', 'f64_random'} (TFLOP/s)."""
+    out, acc = {}, {}
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r05_mfma_power.log")):
+            if "TFLOP/s" not in line:
+                continue
+            key = ("f64" if "f64_16x16x4" in line else "f16") + ("_random" if "random" in line else "_quiet")
+            acc.setdefault(key, []).append(float(line.split("TFLOP/s")[0].split()[-1]))
+        out = {k: sum(v) / len(v) for k, v in acc.items()}
+    except Exception:      # noqa: BLE001 — the log is an annotation, not part of the measurement
+        pass
+    return out
+
+
 def main():
     a = parse()
     wd = int(os.environ.get("DM_BENCH_WATCHDOG", "0"))
@@ -564,6 +579,13 @@ def main():
     if rank == 0:
         avg_ms = kernel_ms / max(n_launch, 1)
         roof = roofline(mode, rows, avg_ms, E, L, kern_name)
+        sus_ = sustained_mfma_tflops()
+        if sus_.get("f16_random") and "mfma_issued_tflops_f16" in roof:
+            # what the matrix pipe SUSTAINS (tools/mfma_power_microbench.hip: a bare MFMA stream, two waves per SIMD, no memory traffic, ~15 ms):
+            # the nominal peak is the issue rate at 2.4 GHz; under the switching activity of random operands the chip holds a lower clock
+            roof["mfma_sustained_tflops_f16"] = {"quiet_operands": sus_.get("f16_quiet"), "random_operands": sus_["f16_random"],
+                                                 "source": "profiles/r05_mfma_power.log (tools/mfma_power_microbench.hip on the same MI355X pool)"}
+            roof["issued_frac_of_sustained_random_operand_rate"] = roof["mfma_issued_tflops_f16"] / sus_["f16_random"]
         roof.update({"launches": n_launch, "gather_gbps": rows * (4 * E + 4) / (avg_ms * 1e-3) / 1e9,
                      "second_pass_ms_avg": (defer_ms / n_defer) if n_defer else 0.0,
                      "clock_mhz_under_load": clk_mhz, "socket_power_w_under_load": pw_w, "peak_clock_mhz": 2400.0})
@@ -941,6 +963,12 @@ def main():
                                   "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / peak_mm, "kernel_ms_avg": gemm_ms, "traffic": None,
                                   "flops_per_user": 2 * Dd * Kd * Ld * Ed,
                                   "note": "the dominant kernel of the search (%.0f %% of the kernel time)" % (100.0 * gemm_ms / max(kms_b / nsd, 1e-9))}
+                sus_ = sustained_mfma_tflops()
+                k_ = "f64_random" if tag == "f64" else "f16_random"
+                if sus_.get(k_):      # the sustained rate of a bare MFMA stream on random operands (tools/mfma_power_microbench.hip); split-fp16: three MFMAs per product
+                    sp_ = sus_[k_] / (1.0 if tag == "f64" else 3.0)
+                    rl["roofline"]["peak_sustained_random_operands"] = sp_
+                    rl["roofline"]["frac_of_sustained"] = rl["roofline"]["achieved"] / sp_
                 # operand requests of the tiled GEMM: every row tile's A operand (gathered history rows) is read once per column tile and every
                 # column tile's B operand once per row tile, through the L1 / L2 fabric
                 tile_ = 256 if x_tiles else 128
