@@ -323,6 +323,8 @@ def sustained_mfma_tflops():
         for line in open(os.path.join(ROOT, "profiles", "r05_mfma_power.log")):
             if "TFLOP/s" not in line:
                 continue
+            if "f64_16x16x4" not in line and "16x16x32_f16" not in line:      # (the log also carries the 32x32x16 shape: 1.56 PFLOP/s on random operands)
+                continue
             key = ("f64" if "f64_16x16x4" in line else "f16") + ("_random" if "random" in line else "_quiet")
             acc.setdefault(key, []).append(float(line.split("TFLOP/s")[0].split()[-1]))
         out = {k: sum(v) / len(v) for k, v in acc.items()}

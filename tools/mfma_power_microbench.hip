@@ -48,6 +48,26 @@ __global__ __launch_bounds__(512) void k16(float *out, int iters) {
   for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool BUSY>
+__global__ __launch_bounds__(512) void k16w(float *out, int iters) {      // v_mfma_f32_32x32x16_f16: twice the flops per operand register read
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++) for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+  h8 a[8], b[8];
+  for (int i = 0; i < 8; i++)
+    for (int e = 0; e < 8; e++) {
+      const uint64_t s = mix(threadIdx.x * 128 + i * 8 + e + 1);
+      const unsigned short ua = BUSY ? (unsigned short)((s & 0x83ff) | 0x3c00) : 0x3c00, ub = BUSY ? (unsigned short)(((s >> 16) & 0x83ff) | 0x2000) : 0x2000;
+      a[i][e] = __builtin_bit_cast(_Float16, ua); b[i][e] = __builtin_bit_cast(_Float16, ub);
+    }
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 7], b[(i + (i >> 3)) & 7], acc[i & 3], 0, 0, 0);
+  }
+  float s = 0;
+  for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][15];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <typename K, typename T> void run(const char *name, K kern, T *out, int iters, double flops_per_mfma) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   kern<<<256, 512>>>(out, 100);
@@ -63,6 +83,8 @@ int main() {
     run("v_mfma_f64_16x16x4_f64, random operands", k64<true>, (double *)out, 20000, 2048.0);
     run("v_mfma_f32_16x16x32_f16, quiet operands", k16<false>, (float *)out, 40000, 16384.0);
     run("v_mfma_f32_16x16x32_f16, random operands", k16<true>, (float *)out, 40000, 16384.0);
+    run("v_mfma_f32_32x32x16_f16, quiet operands", k16w<false>, (float *)out, 20000, 32768.0);
+    run("v_mfma_f32_32x32x16_f16, random operands", k16w<true>, (float *)out, 20000, 32768.0);
   }
   return 0;
 }
