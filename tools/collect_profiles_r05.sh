@@ -34,6 +34,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = dr ]; then
   pmc_set gpurun_out/prof_r05_dr_f64 python tools/dr_bench.py --dtype f64 --rerank 0 --steps 4
   pmc_set gpurun_out/prof_r05_dr_f32 python tools/dr_bench.py --dtype f32 --rerank 0 --steps 4
 fi
+if [ "$WHAT" = drf64 ]; then pmc_set gpurun_out/prof_r05_dr_f64 python tools/dr_bench.py --dtype f64 --rerank 0 --steps 4; fi     # after the conflict-free staging stores
 if [ "$WHAT" = drf32 ]; then pmc_set gpurun_out/prof_r05_dr_f32 python tools/dr_bench.py --dtype f32 --rerank 0 --steps 4; fi     # after the 256 x 256 history GEMM
 if [ "$WHAT" = jtm ]; then pmc_set gpurun_out/prof_r05_jtm python tools/jtm_bench.py 10000000 24; fi     # JTM.optimize at 10 M items: the general-rows split kernel
 if [ "$WHAT" = otmtrain ]; then pmc_set gpurun_out/prof_r05_otmtrain python tools/otm_train_bench.py 24 8192 f64; fi     # fp64 OTM training iteration at train_batch_size 8192
