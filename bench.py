@@ -957,7 +957,8 @@ def main():
             st_bytes = sum((1 + beam_d * d_) * Kd * esz_ for d_ in range(1, Dd)) * float(Ud)
             peak_mm = 78.6 if tag == "f64" else (2516.6 / 3.0)            # fp64 MFMA; split-fp16: three fp16 MFMAs per product
             rl = {}
-            # f32 batches of 12 288 users and more take the 256 x 256 tiles over pre-split operands (dr_kernel.hip.inc: DR_X_MIN_ROWS, DM_DR_GEMM_X)
+            # f32 batches that fill whole rounds of 256 x 256 tiles take the kernel over pre-split operands (dr_kernel.hip.inc: dr_gemm_x_pays, DM_DR_GEMM_X);
+            # the batch sizes this extra runs (16 384 and up) always do
             x_tiles = tag == "f32" and Ud >= 12288 and Ed % 64 == 0 and os.environ.get("DM_DR_GEMM_X", "1") != "0" and a.scorer != "f32"
             if gemm_ms > 0:
                 rl["roofline"] = {"bound": "mfma", "kernel": "dr_gemm_kernel<double>" if tag == "f64" else ("dr_gemm_split_x_kernel" if x_tiles else "dr_gemm_split_kernel"),

@@ -457,7 +457,7 @@ typedef struct dm_dr_model {
 /* replaces the state DeepRetrieval.loadModel / LayerModel / RerankModel hold (D/model/DeepRetrieval.scala:90-106);
  * also precomputes the per-(layer, position) node tables, see DESIGN.md.  Float models with E % 64 == 0 additionally keep a second
  * copy of the item / node embedding rows (4 E bytes per row, as the first) split into fp16 hi/lo records for the 256 x 256 history GEMM
- * of batches of 12 288 users and more; DM_DR_GEMM_X=0 in the environment at load time skips that copy and its kernel. */
+ * of batches that fill whole rounds of its tiles (4 096 users, 8 192 and more at config 5's shape); DM_DR_GEMM_X=0 in the environment at load time skips that copy and its kernel. */
 int dm_dr_load_model(dm_handle_t h, const dm_dr_model *model);
 /* MappingOp.pathItemMapping (D/model/MappingOp.scala:14-28) as a CSR over DISTINCT paths: path_nodes [n_paths x D],
  * items of path i = items[item_off[i] .. item_off[i+1]) in the order searchCandidate should yield them

@@ -264,7 +264,7 @@ def test_sliced_pipeline_equals_one_kernel_on_a_batch(dtype, dr_search_path):
 
 @pytest.mark.parametrize("K,L,E,U", [(100, 13, 64, 600), (86, 3, 128, 1061), (1000, 10, 128, 12288 + 37)])
 def test_presplit_history_gemm_is_bit_identical_to_the_128_tile_kernel(K, L, E, U, dr_search_path):
-    """Batches of 12 288 users and more run the history GEMM on 256 x 256 tiles over operands split into fp16 hi/lo records once at model
+    """Batches that fill whole rounds of 256 x 256 tiles (dr_gemm_x_pays) run the history GEMM on them, over operands split into fp16 hi/lo records once at model
     load and copied global -> LDS directly (dr_gemm_split_x_kernel).  Same split arithmetic and the same order of MFMAs per accumulator
     as the 128 x 128 kernel, so the two must agree in every bit: paths, probabilities and counts of a whole search, on shapes that leave
     ragged row and column tiles, idle XCD slots, E = 64 (two stages per history position) and padding ids."""
