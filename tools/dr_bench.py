@@ -48,8 +48,19 @@ def main():
     eng.synchronize()
     dt = time.perf_counter() - t0
     nl, ms = eng.timing_get()
-    out["beam_search"] = {"users_per_s": U * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_ms_per_step": ms / a.steps,
-                          "launches_per_step": nl / a.steps}
+    out["beam_search"] = {"users_per_s": U * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "device_ms_per_step": ms / a.steps}
+    # breakdown pass: an event pair around every launch (DM_DR_TIME_LAUNCHES=1, read per call) — the pairs drain the GPU between the kernels,
+    # so this pass is slower than the timed one above and only its per-kernel times are kept
+    os.environ["DM_DR_TIME_LAUNCHES"] = "1"
+    eng.synchronize(); eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.dr_beam_search_dev(d_seq, U, a.beam, d_paths, d_probs, d_cnt)
+    eng.synchronize()
+    dtb = time.perf_counter() - t0
+    os.environ.pop("DM_DR_TIME_LAUNCHES", None)
+    nl, ms = eng.timing_get()
+    out["beam_search"].update({"kernel_ms_per_step": ms / a.steps, "launches_per_step": nl / a.steps, "ms_per_step_with_per_launch_events": dtb / a.steps * 1e3})
     per = {}
     for kind, name in ((0, "gemm / single kernel"), (11, "layer0"), (12, "stats_d1"), (13, "select_d1"), (14, "stats_d2"), (15, "select_d2"), (23, "select_d1_todo_pass"), (25, "select_d2_todo_pass")):
         n_, ms_ = eng.timing_get_kind(kind)
