@@ -7,7 +7,8 @@ histories are already resident in HBM; the steps cycle through 8 distinct shards
 N GPUs = N independent user populations (replicated table, no data-path collective; the harness barrier and the
 slowest-rank clock use torch.distributed, the training extra's gradient exchange dismember_amd.comm = RCCL in the library).
 
-Prints ONE JSON line (rank 0).
+Prints ONE compact JSON line (rank 0, < 4 KB: compact_line()); the full result object goes to bench_full.json (write_full()).
+`--gpus N` with no launcher around it starts its own N ranks (launch_ranks()).
 """
 import argparse
 import ctypes as C
@@ -222,7 +223,7 @@ def cpu_baseline(tree, w, E, L, num_index, seqs, beam, topk, n_users):
     t0 = time.perf_counter()
     ids, sc, cnt = otree.recommend_batch(din, seqs[:n_users], topk, beam, n_threads=cores)
     dt = time.perf_counter() - t0
-    return dict(value=n_users / dt, unit="users/s", cores=cores, kind="port",
+    return dict(value=n_users / dt, unit="users/s", cores=cores, kind="port", sample_short="%d users of the headline workload, %.1f s, %d threads" % (n_users, dt, cores),
                 sample="%d users of the same workload, %.1f s wall, oracle/libdm_oracle.so (C restatement of the "
                        "reference path, one pthread per usable core (cgroup quota) over contiguous user ranges)" % (n_users, dt)), one, (ids, cnt, otree, din)
 
@@ -272,7 +273,7 @@ def init_distributed():
         return None, rank, world, local
     import torch
     import torch.distributed as dist
-    if os.environ.get("DM_BENCH_BACKEND", "nccl") == "nccl":
+    if os.environ.get("DM_BENCH_BACKEND", "gloo" if "DM_FORCE_DEVICE" in os.environ else "nccl") == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:                                         # single-GPU smoke test of the N > 1 path (DM_FORCE_DEVICE=0)
@@ -333,8 +334,179 @@ def sustained_mfma_tflops():
     return out
 
 
+def _r(x, nd=4):
+    """Round floats for the compact line (keeps it short; the full object keeps every digit)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    if abs(x) >= 1000:
+        return round(x, 1)
+    return float("%.*g" % (nd + 1, x))
+
+
+def _dig(o, *path):
+    for k in path:
+        if not isinstance(o, dict) or k not in o:
+            return None
+        o = o[k]
+    return o
+
+
+COMPACT_LIMIT = 4096
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def compact_line(full, full_path=None):
+    """The ONE stdout line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and one scalar per extra, no prose,
+    under COMPACT_LIMIT bytes (tests/test_bench_line.py).  Everything else lives in the full object (bench_full.json)."""
+    cfg, roof, cpu = full.get("config", {}), full.get("roofline", {}), full.get("cpu_baseline")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 5)
+    out["dtype"] = "f32"            # the path computes in fp32 (the split scorer feeds fp32 values as fp16 hi+lo pairs, fp32 accumulation)
+    out["data"] = "synthetic"
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:160]}
+    for k in ("items", "depth", "embed", "beam", "topk", "seq_len", "users_per_step_per_gpu", "user_shards", "parallelism", "scored_rows_per_user", "scorer"):
+        if k in cfg:
+            out["config"][k] = _r(cfg[k], 5)
+    out["roofline"] = {k: _r(roof.get(k), 5) for k in ("bound", "kernel", "kernel_ms_avg", "achieved", "peak", "unit", "frac", "traffic")}
+    for k_out, k_in in (("useful_frac_of_fp16_peak", "useful_frac_of_fp16_peak"), ("issued_frac_of_fp16_peak", "issued_frac_of_fp16_peak"),
+                        ("issued_frac_of_sustained", "issued_frac_of_sustained_random_operand_rate"), ("launches", "launches"),
+                        ("clock_mhz", "clock_mhz_under_load"), ("power_w", "socket_power_w_under_load")):
+        if roof.get(k_in) is not None:
+            out["roofline"][k_out] = _r(roof[k_in])
+    if isinstance(cpu, dict):
+        out["cpu_baseline"] = {"value": _r(cpu.get("value"), 5), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                               "sample": str(cpu.get("sample_short") or cpu.get("sample", ""))[:96]}
+    else:
+        out["cpu_baseline"] = None
+    rec = full.get("recall_at_%s_vs_bruteforce" % cfg.get("topk", 200)) or full.get("recall_at_200_vs_bruteforce")
+    out["recall_at_200_vs_bruteforce"] = _r(rec.get("value") if isinstance(rec, dict) else rec)
+    scal = {
+        "recall_at_200_vs_bruteforce_trained": _dig(full, "extra_trained_recall", "recall_trained"),
+        "recall_at_200_vs_bruteforce_before_training": _dig(full, "extra_trained_recall", "recall_untrained"),
+        "id_lists_identical_to_cpu_oracle": full.get("id_lists_identical_to_cpu_oracle"),
+        "id_lists_compared_with_cpu_oracle": full.get("id_lists_compared_with_cpu_oracle"),
+        "near_tie_explained_frac": full.get("near_tie_explained_frac"),
+        "cpu_baseline_1core_users_per_s": _dig(full, "cpu_baseline_1core", "value"),
+        "host_buffer_users_per_s": full.get("host_buffer_users_per_s"),
+        "rccl_nranks": full.get("rccl_nranks"),
+        "comm_transport": full.get("comm_transport"),
+        "per_rank_users_per_s": full.get("per_rank_users_per_s"),
+        "diverse_beams_users_per_s": full.get("diverse_beams_users_per_s"),
+        "iid_table_users_per_s": _dig(full, "extra_diverse_beams", "iid_table_rho0", "users_per_s"),
+        "other_scorer_f32_users_per_s": _dig(full, "extra_other_scorer", "users_per_s"),
+        "other_scorer_f32_frac": _dig(full, "extra_other_scorer", "roofline", "frac"),
+        "long_history_L24_users_per_s": full.get("long_history_L24_users_per_s"),
+        "otm_serve_users_per_s": _dig(full, "extra_otm_serve", "users_per_s"),
+        "otm_fp64_users_per_s": _dig(full, "extra_otm_fp64", "users_per_s"),
+        "otm_fp64_frac": _dig(full, "extra_otm_fp64", "roofline", "frac"),
+        "otm_fp64_train_iter_8192_s": _dig(full, "extra_otm_fp64", "train_iteration_batch_8192", "seconds"),
+        "jtm_optimize_s": _dig(full, "extra_jtm_optimize", "seconds"),
+        "jtm_optimize_din_rows_per_s": _dig(full, "extra_jtm_optimize", "din_rows_per_s"),
+        "jtm_rows_kernel_issued_frac": _dig(full, "extra_jtm_optimize", "roofline", "frac"),
+        "jtm_scoring_items_per_s": _dig(full, "extra_jtm_scoring", "items_per_s"),
+        "c1_1m_tree_users_per_s": _dig(full, "extra_1m_item_tree", "users_per_s"),
+        "c1_1m_tree_frac": _dig(full, "extra_1m_item_tree", "roofline", "frac"),
+        "c1_1m_tree_recall_at_200": _dig(full, "extra_1m_item_tree", "recall_at_200_vs_bruteforce"),
+        "train_step_ms": _dig(full, "extra_train_step", "ms_per_step"),
+        "dr_f64_users_per_s": _dig(full, "extra_deep_retrieval", "beam_search_users_per_s"),
+        "dr_f64_kernel_ms": _dig(full, "extra_deep_retrieval", "beam_search_kernel_ms_per_step"),
+        "dr_f32_users_per_s": _dig(full, "extra_deep_retrieval", "f32_split", "beam_search_users_per_s"),
+        "dr_f32_kernel_ms": _dig(full, "extra_deep_retrieval", "f32_split", "beam_search_kernel_ms_per_step"),
+        "c0_tdm_recommend_ms": _dig(full, "extra_config0_latency", "ms_per_call"),
+        "c0_cpu_oracle_ms": _dig(full, "extra_config0_latency", "cpu_oracle_ms_per_call"),
+        "c0_recall_trained_beam200": _dig(full, "extra_config0_latency", "recall_vs_bruteforce_trained_model", "beam200_top200"),
+        "comm_error": (str(full["comm_error"])[:120] if full.get("comm_error") else None),
+    }
+    for k, v in scal.items():
+        if v is None:
+            continue
+        out[k] = [_r(x, 5) for x in v] if isinstance(v, (list, tuple)) else _r(v, 5)
+    if full_path:
+        out["full"] = full_path
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:                    # cannot happen with the keys above; never let an extra cost the headline
+        for k in list(scal):
+            out.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_full(full):
+    """The whole result object (the lab notebook) goes to files, not to stdout: bench_full.json beside bench.py and, when the directory
+    exists, gpurun_out/bench_full.json.  Returns the name quoted in the compact line."""
+    txt = json.dumps(full, indent=1)
+    name = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(txt + "\n")
+                name = name or os.path.relpath(os.path.join(d, "bench_full.json"), ROOT)
+        except OSError:
+            pass
+    return name
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` as typed (no torchrun around it): start N ranks of this same command, one per GPU, with the launcher
+    environment init_distributed() reads; rank 0 prints the line.  Fails loudly when the node has fewer than N devices (unless
+    DM_FORCE_DEVICE pins every rank to one device for a smoke test of the N > 1 path)."""
+    import socket
+    import subprocess
+    from dismember_amd import _native
+    n = C.c_int(0)
+    rc = _native.lib().dm_device_count(C.byref(n))
+    if rc != 0:
+        sys.exit("bench.py: dm_device_count failed (%d): no usable HIP device" % rc)
+    if "DM_FORCE_DEVICE" not in os.environ and n.value < a.gpus:
+        sys.exit("bench.py: --gpus %d asked for, %d HIP device(s) visible; refusing to run a smaller job under that label "
+                 "(DM_FORCE_DEVICE=0 DM_COMM_TRANSPORT=host runs every rank on one device as a smoke test)" % (a.gpus, n.value))
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * a.gpus
+    try:
+        while any(c is None for c in rcs):
+            for i, p_ in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = p_.poll()
+            if any(c not in (None, 0) for c in rcs):
+                break
+            time.sleep(0.2)
+    finally:
+        for i, p_ in enumerate(procs):             # a failed rank takes the job down: its peers would wait in a barrier for ever
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in procs:
+            try:
+                p_.wait(20)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+    bad = [(i, c) for i, c in enumerate(rcs) if c not in (0,)]
+    if bad:
+        sys.exit("bench.py: rank %d exited with %s" % (bad[0][0], bad[0][1]))
+    sys.exit(0)
+
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
     wd = int(os.environ.get("DM_BENCH_WATCHDOG", "0"))
     if wd > 0:                         # debugging aid: dump every thread's stack and exit if the run is still alive after `wd` seconds
         import faulthandler
@@ -408,8 +580,12 @@ def main():
     for i in range(a.steps):
         eng.tdm_beam_search_dev(d_seqs[i % NSH], U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)
     sync(); barrier()
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt)
+    dt_own = time.perf_counter() - t0
+    dt = max_over_ranks(dt_own)
+    per_rank_rate = [U * a.steps / dt_own]
+    if dist is not None:
+        per_rank_rate = [None] * world
+        dist.all_gather_object(per_rank_rate, U * a.steps / dt_own)
     n_launch, kernel_ms = eng.timing_get_kind(0)                # the search kernel proper (HIP events on the library's stream)
     n_defer, defer_ms = eng.timing_get_kind(1)                  # second pass over deferred users (one-wave kernel only)
     kern_name = eng.last_beam_kernel()
@@ -607,8 +783,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if mode == "f32" else "f32 (operands as fp16 hi+lo pairs on the fp16 matrix pipe, fp32 accumulation)", "data": "synthetic (tree-correlated N(0,0.05) node embeddings rho=%.2f, N(0,0.05) DIN weights, Zipf(1.0) histories)" % a.rho,
             "config": {"workload": "TDM beam-search serving, synthetic %d-item depth-%d binary tree, %d-d emb, "
-                                   "beam=%d, topk=%d, L=%d, 1xMI355X per shard (the catalogue BASELINE.json's metric names; 17.2 GB table)"
+                                   "beam=%d, topk=%d, L=%d"
                                    % (a.items, depth, E, a.beam, a.topk, L),
+                       "items": a.items, "depth": depth, "embed": E, "beam": a.beam, "topk": a.topk, "seq_len": L,
                        "users_per_step_per_gpu": U, "user_shards": NSH, "distinct_users_per_gpu": U * NSH,
                        "parallelism": "user-sharded x%d, replicated table" % world,
                        "scored_rows_per_user": rows / U},
@@ -628,7 +805,7 @@ def main():
         res["roofline"]["traffic"] = None
         res["roofline"]["algorithmic_gather_bytes_per_launch"] = rows * (4 * E + 4)
         why = None
-        for tag in ("r05", "r04", "r03"):        # newest committed profile set first
+        for tag in ("r06", "r05", "r04", "r03"):        # newest committed profile set first
             pname = "%s_summary.json" % tag if mode != "f32" else "%s_f32_summary.json" % tag
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", pname)))
@@ -639,7 +816,7 @@ def main():
                 pms = prof["kernel_trace"]["avg_ns"] / 1e6
                 # the profile is only quoted for the kernel that was just timed, on this workload, and when its own average
                 # duration agrees with this run's HIP-event average to 5 % (another kernel version or box state would not)
-                if pw["workload"] != res["config"]["workload"] or pw["users_per_step_per_gpu"] != U:
+                if not pw["workload"].startswith(res["config"]["workload"]) or pw["users_per_step_per_gpu"] != U:
                     why = "profiles/%s was taken on another workload" % pname
                 elif kern_name not in prof["kernel_trace"]["kernel"]:
                     why = "profiles/%s profiled %s, this run timed %s" % (pname, prof["kernel_trace"]["kernel"], kern_name)
@@ -1327,8 +1504,12 @@ def main():
             res_main["extra_train_step"] = train
         if dist is not None:
             res_main["comm_transport"] = comm_transport
+            res_main["per_rank_users_per_s"] = per_rank_rate
+            nr_ = [x for x in (_dig(train, "exchange", "rccl_nranks"), _dig(jtm_full, "sharding", "rccl_nranks")) if x is not None]
+            res_main["rccl_nranks"] = max(nr_) if nr_ else 0
             res_main["comm_error"] = comm_err or jtm_comm_err_top
-        print(json.dumps(res_main))
+        print(compact_line(res_main, write_full(res_main)))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
