@@ -1607,7 +1607,6 @@ int dm_tdm_beam_search_dev(dm_handle_t h, const int32_t *d_seq_item_ids, int64_t
                            float *d_out_scores, int32_t *d_out_counts) {
   if (!h) return DM_ERR_INVALID;
   DM_CLONE_ENTER(h);
-  DM_CLONE_ENTER(h);
   if (!d_seq_item_ids || !opts || !d_out_item_ids || !d_out_scores || !d_out_counts) return fail(h, DM_ERR_INVALID, "dm_tdm_beam_search_dev: NULL argument");
   HIPCHK(h, hipSetDevice(h->device));
   int mb = opts->beam;

@@ -122,3 +122,19 @@ def dr_path_items_fast(item_paths, K):
         paths[:, d] = c % K
         c = c // K
     return paths, off, item
+
+
+def make_tree_consistent_interactions(leaf_ids, n_users, L, rng, spread=64.0, pad_p=0.15):
+    """(histories, targets) whose structure FOLLOWS the tree: a user is an anchor position in the leaf order, its history items sit a
+    Laplace(spread) number of leaves away from the anchor and its target a Laplace(spread / 4) number away — so an ancestor of the
+    target is, level by level, the subtree most of the history lies in (what TDM's training makes the scorer learn,
+    T/dataset/TDMTrainSet + NegativeSampler: positives = the target's ancestors).  leaf_ids is in leaf-code order (make_tree)."""
+    n = leaf_ids.size
+    anchor = rng.integers(0, n, n_users)
+    off = np.rint(rng.laplace(0.0, spread, (n_users, L))).astype(np.int64)
+    seq = leaf_ids[np.clip(anchor[:, None] + off, 0, n - 1)].astype(np.int32)
+    npad = rng.binomial(L, pad_p, n_users)
+    seq[np.arange(L)[None, :] < npad[:, None]] = 0
+    toff = np.rint(rng.laplace(0.0, spread / 4.0, n_users)).astype(np.int64)
+    tgt = leaf_ids[np.clip(anchor + toff, 0, n - 1)].astype(np.int32)
+    return seq, tgt

@@ -225,6 +225,35 @@ def test_split_history_gemm_vs_fp32_gemm():
     assert not np.array_equal(v0, v1)        # the two GEMMs really are different kernels
 
 
+def test_split_scorer_by_name_is_refused_where_the_split_gemm_does_not_exist():
+    """E = 32 (not a multiple of 64): no split planes are built, DM_SCORER_AUTO runs the fp32 GEMM — and asking for SPLIT_F16 by name is
+    DM_ERR_UNSUPPORTED, not a silent fp32 run; E = 1088 (> 1024) pads histories with a zero block as long as a row's records."""
+    eng, orc, w, rng = make(50, 2, 6, 32, 400, 19, np.float32, scale=0.1, with_paths=False)
+    seqs = histories(rng, 8, 6, 400)
+    eng.set_scorer_mode("auto")
+    p0, v0, c0 = eng.dr_beam_search(seqs, 10)
+    eng.set_scorer_mode("split_f16")
+    with pytest.raises(DismemberError) as e:
+        eng.dr_beam_search(seqs, 10)
+    assert e.value.code == -5
+    eng.set_scorer_mode("f32")
+    p1, v1, c1 = eng.dr_beam_search(seqs, 10)
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    eng.close()
+    K, D, L, E, n = 32, 2, 4, 1088, 300
+    eng, orc, w, rng = make(K, D, L, E, n, 23, np.float32, scale=0.02, with_paths=False)
+    seqs = histories(rng, 40, L, n)
+    eng.set_scorer_mode("f32")
+    p0, v0, c0 = eng.dr_beam_search(seqs, 8)
+    eng.set_scorer_mode("auto")
+    p1, v1, c1 = eng.dr_beam_search(seqs, 8)
+    same = sum(np.array_equal(p0[u], p1[u]) for u in range(len(seqs)))
+    assert same >= 0.9 * len(seqs), same
+    for u in range(len(seqs)):
+        if np.array_equal(p0[u], p1[u]):
+            np.testing.assert_allclose(v1[u], v0[u], rtol=5e-5, atol=0)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sliced_pipeline_equals_one_kernel_on_a_batch(dtype, dr_search_path):
     """600 users (above the default switch-over of 512), BASELINE config 5's shape: the column-sliced pipeline — history factors and
