@@ -143,6 +143,7 @@ def parse():
     ap.add_argument("--host-buffer-steps", type=int, default=3, help="steps of the headline workload through the host-buffer entry point (0 = skip)")
     ap.add_argument("--jtm-full", type=int, default=1, help="also time the FULL JTM.optimize over the 10M-item catalogue (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--jtm-rows", type=int, default=4, help="training rows per item of the full JTM.optimize extra")
+    ap.add_argument("--trained-recall-steps", type=int, default=6000, help="TDMTrainer steps (1024 tree-consistent targets each) before recall@topk vs brute force is measured again on the 1M-item tree; 0 = skip")
     ap.add_argument("--otm64", type=int, default=1, help="also time OTM serving and one OTM training iteration in the reference's fp64 (BASELINE configs[2]); 0 = skip")
     a = ap.parse_args()
     if a.big is not None:
@@ -390,6 +391,7 @@ def compact_line(full, full_path=None):
     scal = {
         "recall_at_200_vs_bruteforce_trained": _dig(full, "extra_trained_recall", "recall_trained"),
         "recall_at_200_vs_bruteforce_before_training": _dig(full, "extra_trained_recall", "recall_untrained"),
+        "target_in_top200_trained": _dig(full, "extra_trained_recall", "target_in_beam_topk_trained"),
         "id_lists_identical_to_cpu_oracle": full.get("id_lists_identical_to_cpu_oracle"),
         "id_lists_compared_with_cpu_oracle": full.get("id_lists_compared_with_cpu_oracle"),
         "near_tie_explained_frac": full.get("near_tie_explained_frac"),
@@ -409,7 +411,9 @@ def compact_line(full, full_path=None):
         "otm_fp64_train_iter_8192_s": _dig(full, "extra_otm_fp64", "train_iteration_batch_8192", "seconds"),
         "jtm_optimize_s": _dig(full, "extra_jtm_optimize", "seconds"),
         "jtm_optimize_din_rows_per_s": _dig(full, "extra_jtm_optimize", "din_rows_per_s"),
-        "jtm_rows_kernel_issued_frac": _dig(full, "extra_jtm_optimize", "roofline", "frac"),
+        "jtm_rows_kernel_gather_frac": _dig(full, "extra_jtm_optimize", "roofline", "frac"),
+        "jtm_rows_kernel_issued_frac_fp16": _dig(full, "extra_jtm_optimize", "roofline", "issued_frac_of_fp16_peak"),
+        "jtm_rows_kernel_ms_avg": _dig(full, "extra_jtm_optimize", "roofline", "kernel_ms_avg"),
         "jtm_scoring_items_per_s": _dig(full, "extra_jtm_scoring", "items_per_s"),
         "c1_1m_tree_users_per_s": _dig(full, "extra_1m_item_tree", "users_per_s"),
         "c1_1m_tree_frac": _dig(full, "extra_1m_item_tree", "roofline", "frac"),
@@ -945,10 +949,12 @@ def main():
         prep = time.perf_counter() - t0
         sync(); barrier()
         tim = {}
+        eng.timing_reset()
         t0 = time.perf_counter()
         projf = jtf.optimize(timing=tim, as_array=True)
         sync(); barrier()
         dtf = max_over_ranks(time.perf_counter() - t0)
+        n_rl, rows_ms = eng.timing_get_kind(30)         # the general-rows scorer's launches (HIP events on the library's stream)
         first_leaf = (1 << depth) - 1
         steps_j = (depth + 1) // 2
         din_rows = int(items_s.size) * nrow * 6 * steps_j
@@ -972,6 +978,30 @@ def main():
                                            "of the projection.  synthetic_catalogue_generation_s is this bench drawing 40 M synthetic training rows with numpy "
                                            "(round 4 reported it as host_preparation_s): a caller brings its rows, the library never runs it",
                     "bijection_onto_leaves": bool(np.unique(projf).size == projf.size and int(projf.min()) >= first_leaf)}
+        if n_rl:
+            # the scorer of config 4: dm_din_rows_split_l_kernel<E, L>.  Per scored row 2(2LE + 2E^2 + E) algorithmic flops (merged M = W1b att.W),
+            # 192 fp16 MFMAs per 16-row tile issued (3 per product), and (1 + L) embedding rows gathered — 1 + L / chain unique ones, since the
+            # 2^(gap+1) - 2 chain nodes of a training row are scored against one history.  Neither pipe bounds it: the fractions say how far.
+            rows_l = (int(tim["sharding"]["items_scored"]) if tim.get("sharding") else int(items_s.size) * steps_j) * nrow * 6
+            t_ = rows_ms * 1e-3
+            fl_ = 2 * (2 * L * E + 2 * E * E + E)
+            iss_ = 2 * 3 * (E // 32) * (E // 16) * 16384 / 16.0
+            uniq_ = rows_l * (1.0 + L / 6.0) * 4 * E
+            jtm_full["roofline"] = {"bound": "l2", "kernel": "dm_din_rows_split_l_kernel<%d, %d>" % (E, L), "launches": n_rl, "kernel_ms_avg": rows_ms / n_rl,
+                                    "kernel_ms_total": rows_ms, "rows": rows_l,
+                                    "achieved": uniq_ / t_ / 1e9, "peak": 9500.0, "unit": "GB/s", "frac": uniq_ / t_ / 1e9 / 9500.0, "traffic": None,
+                                    "peak_source": "tools/gather_microbench.hip: what the L1 / L2 fabric delivers to 1 024 gathering waves (DESIGN.md)",
+                                    "unique_row_bytes": uniq_, "requested_gather_gbps": rows_l * (1 + L) * 4 * E / t_ / 1e9,
+                                    "algorithmic_tflops": rows_l * fl_ / t_ / 1e12, "mfma_issued_tflops_f16": rows_l * iss_ / t_ / 1e12,
+                                    "issued_frac_of_fp16_peak": rows_l * iss_ / t_ / 1e12 / PEAK_MFMA_F16_TFLOPS}
+            try:
+                pj_ = json.load(open(os.path.join(ROOT, "profiles", "r06_jtm_summary.json")))
+                if "dm_din_rows_split_l_kernel" in pj_["kernel_trace"]["kernel"] and abs(pj_["kernel_trace"]["avg_ns"] / 1e6 - rows_ms / n_rl) < 0.15 * rows_ms / n_rl:
+                    jtm_full["roofline"]["traffic"] = pj_["hbm_traffic_per_launch_bytes"]["total_corrected"] * n_rl
+                    jtm_full["roofline"]["profiled_kernel_ms_avg"] = pj_["kernel_trace"]["avg_ns"] / 1e6
+                    jtm_full["roofline"]["profiled_mfma_busy_frac"] = pj_.get("mfma_pipe_utilisation")
+            except Exception:       # noqa: BLE001 — the PMC summary is an annotation
+                pass
         sh = tim.get("sharding")
         if sh is not None:
             # what THIS run did, from the library's own counters (rank 0's view; per-rank item counts differ by at most one)
@@ -1086,6 +1116,48 @@ def main():
                                      "host_syncs_per_step": st["host_syncs"], "rows_per_s_per_rank": Tt * per * nts / dtt}
         elif comm_note:
             train = {"skipped": comm_note}
+    stage("extra recall@topk vs brute force on a TRAINED scorer (1M-item tree)")
+    # ---- extra: recall@topk vs brute force before / after training at scale (round-5 verdict, next #7).  On random weights the tree is
+    # not a max-heap of the scores and the recall says nothing about the search; the reference evaluates trained models
+    # (T/evaluation/Evaluator.scala:32-71).  Here: the 1M-item engine, fresh synthetic weights, N TDMTrainer steps (level-wise negatives on
+    # the device, DIN fwd+bwd, Adam) on interactions whose targets sit near the user's history in the tree; same held-out users before and after.
+    trained = None
+    if a.small and default_cfg and a.train and a.trained_recall_steps > 0 and rank == 0:
+        try:
+            from dismember_amd.trainer import TDMTrainer
+            if comm is not None:
+                eng.attach_comm(None)
+            eng.load_weights_din_synthetic(E, ni2, synth.SEED, tree_depth=depth2, rho=a.rho)
+            eng.set_scorer_mode(a.scorer)
+            neg = np.array(a.params["layer_negative_counts_list"], np.int32)
+            Tn, lr_, spread_ = 1024, 3e-3, 64.0
+            tr2 = TDMTrainer(eng, neg, lr=lr_, comm=None, seed=synth.SEED, sampler="device", with_prob=a.params["sample_with_probability"])
+            ev_seq, ev_tgt = synth.make_tree_consistent_interactions(tree2["leaf_ids"], 512, L, np.random.default_rng(synth.SEED + 991), spread_)
+
+            def _recall():
+                i_, _, c_ = eng.tdm_beam_search(ev_seq, a.beam, a.topk)
+                b_, _, bc_ = eng.tdm_bruteforce_topk(ev_seq, a.topk)
+                rec_ = np.mean([len(set(i_[u, :c_[u]].tolist()) & set(b_[u, :bc_[u]].tolist())) / float(a.topk) for u in range(len(ev_seq))])
+                hit_ = np.mean([int(ev_tgt[u]) in set(i_[u, :c_[u]].tolist()) for u in range(len(ev_seq))])
+                bhit_ = np.mean([int(ev_tgt[u]) in set(b_[u, :bc_[u]].tolist()) for u in range(len(ev_seq))])
+                return float(rec_), float(hit_), float(bhit_)
+            r0_ = _recall()
+            trng2 = np.random.default_rng(synth.SEED + 17)
+            t0 = time.perf_counter()
+            for _ in range(a.trained_recall_steps):
+                s_, t_ = synth.make_tree_consistent_interactions(tree2["leaf_ids"], Tn, L, trng2, spread_)
+                tl_ = tr2.step(s_, t_)
+            eng.synchronize()
+            dtr_ = time.perf_counter() - t0
+            r1_ = _recall()
+            trained = {"what": "recall@%d of the beam search vs brute force under the SAME weights, 512 held-out users, before and after training" % a.topk,
+                       "steps": a.trained_recall_steps, "targets_per_step": Tn, "learning_rate": lr_, "leaf_spread": spread_, "train_s": dtr_,
+                       "loss_last_step": tl_, "recall_untrained": r0_[0], "recall_trained": r1_[0],
+                       "target_in_beam_topk_untrained": r0_[1], "target_in_beam_topk_trained": r1_[1], "target_in_bruteforce_topk_trained": r1_[2],
+                       "eval_users": len(ev_seq)}
+        except Exception as ex:       # noqa: BLE001 — an extra must not cost the headline line
+            trained = {"skipped": repr(ex)}
+    barrier()
     stage("extra Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=10")
     # ---- extra: Deep-Retrieval serving, BASELINE configs[4] (row A13): D=3, K=1000, beam=50, 10M items.  The record is the fp64
     #      run (the reference's arithmetic type, deep-retrieval/.../model/LayerModel.scala); the f32 model with the split-fp16
@@ -1502,6 +1574,8 @@ def main():
             res_main["extra_1m_item_tree"] = small
         if train is not None:
             res_main["extra_train_step"] = train
+        if trained is not None:
+            res_main["extra_trained_recall"] = trained
         if dist is not None:
             res_main["comm_transport"] = comm_transport
             res_main["per_rank_users_per_s"] = per_rank_rate

@@ -6,6 +6,7 @@ library is missing or no HIP device is usable, calls fail loudly.
 import ctypes as C
 import os
 import shutil
+import time
 import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
@@ -173,7 +174,16 @@ def build(force=False, verbose=False):
            "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    t_start = time.time()
+    tmp = LIB_PATH + ".tmp%d" % os.getpid()
+    cmd[cmd.index("-o") + 1] = tmp                      # (never a half-written library under the real name)
+    try:
+        subprocess.check_call(cmd)
+        os.utime(tmp, (t_start, t_start))               # a source edited WHILE the compiler ran is newer than the library: next build() rebuilds
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 

@@ -761,7 +761,9 @@ int dm_load_weights_din(dm_handle_t h, int dtype, int E, int64_t num_index, cons
   DM_OWNER_ONLY(h, "dm_load_weights_din");
   if (!compact || num_index <= 0) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: bad arguments");
   if (E < 1 || E > 128)
-    return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 1 .. 128 (sizes other than 16 / 32 / 64 / 128 are zero-padded to the next of them)");
+    return fail(h, DM_ERR_UNSUPPORTED, "dm_load_weights_din: embed size must be 1 .. 128 (sizes other than 16 / 32 / 64 / 128 are zero-padded to the next of them; at E = 256 the "
+                "fp16 hi / lo planes of W1a are 256 KB against 64 KB of AccVGPRs per wave and 160 KB of LDS per CU: the weights would have to stream "
+                "per 128-column slab, ~4.3 x the E = 128 time per scored row — DESIGN.md, not built)");
   if (dtype != DM_F32 && dtype != DM_F64) return fail(h, DM_ERR_INVALID, "dm_load_weights_din: dtype");
   HIPCHK(h, hipSetDevice(h->device));
   h->dtype = dtype;
@@ -955,17 +957,52 @@ static int ensure_rows_split(dm_ctx *h) {
   return DM_OK;
 }
 
+static int next_events(dm_ctx *h, hipEvent_t *a, hipEvent_t *b);
+// HIP-event pair of kind 30 around a general-rows launch (dm_kernel_timing_get_kind: the roofline of JTM's scorer in bench.py)
+struct RowsTimer {
+  dm_ctx *h; hipEvent_t e0 = nullptr, e1 = nullptr; int rc = DM_OK;
+  explicit RowsTimer(dm_ctx *h_) : h(h_) {
+    const int k = h->ev_next_kind; h->ev_next_kind = 30; rc = next_events(h, &e0, &e1); h->ev_next_kind = k;
+    if (rc == DM_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(h, DM_ERR_HIP, "hipEventRecord failed");
+  }
+  int stop() { return (rc == DM_OK && hipEventRecord(e1, h->stream) != hipSuccess) ? fail(h, DM_ERR_HIP, "hipEventRecord failed") : rc; }
+};
+
+template <int E, int LC>
+static int launch_rows_split_EL(dm_ctx *h, const RowsSplitParams &p, int64_t blocks) {
+  const int lds = 4 * E * E * 2 + DM_NWAVES * 2 * (DM_MAXL + 2) * 16 * 4 + 2 * E * 4;      // weight planes + the per-wave index staging + b1, w2
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_din_rows_split_l_kernel<E, LC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  RowsTimer tm(h);
+  if (tm.rc != DM_OK) return tm.rc;
+  hipLaunchKernelGGL((dm_din_rows_split_l_kernel<E, LC>), dim3((unsigned)blocks), dim3(DM_BLOCK), lds, h->stream, p);
+  HIPCHK(h, hipGetLastError());
+  return tm.stop();
+}
+
+// History lengths with a counted-load instance (rows_kernel.hip.inc: dm_din_rows_split_l_kernel); every other length takes the generic
+// kernel — the same arithmetic in the same order, bit-identical results (tests/test_gpu_precision.py).  DM_ROWS_GENERIC=1 forces it.
 template <int E>
 static int launch_rows_split_E(dm_ctx *h, const RowsSplitParams &p) {
-  const int lds = 4 * E * E * 2;
-  HIPCHK(h, hipFuncSetAttribute((const void *)dm_din_rows_split_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int64_t tiles = (p.B + 15) / 16;
   int64_t blocks = (tiles + DM_NWAVES - 1) / DM_NWAVES;
   if (blocks > h->n_cu) blocks = h->n_cu;
   if (blocks < 1) blocks = 1;
+  static const bool generic_only = [] { const char *e_ = getenv("DM_ROWS_GENERIC"); return e_ && e_[0] == '1'; }();
+  if (!generic_only) {
+    switch (p.L) {
+      case 8: return launch_rows_split_EL<E, 8>(h, p, blocks);
+      case 10: return launch_rows_split_EL<E, 10>(h, p, blocks);
+      case 16: return launch_rows_split_EL<E, 16>(h, p, blocks);
+      default: break;
+    }
+  }
+  const int lds = 4 * E * E * 2;
+  HIPCHK(h, hipFuncSetAttribute((const void *)dm_din_rows_split_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  RowsTimer tm(h);
+  if (tm.rc != DM_OK) return tm.rc;
   hipLaunchKernelGGL(dm_din_rows_split_kernel<E>, dim3((unsigned)blocks), dim3(DM_BLOCK), lds, h->stream, p);
   HIPCHK(h, hipGetLastError());
-  return DM_OK;
+  return tm.stop();
 }
 
 // f32 general-rows forward on device buffers (asynchronous on the handle's stream)

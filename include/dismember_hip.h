@@ -507,7 +507,8 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms);
  * one-wave-per-SIMD beam kernel hands to the LDS-fed kernel (one launch per search, empty on most inputs).
  * A Deep-Retrieval search is several launches: by default ONE pair brackets the whole search (kind 0); with
  * DM_DR_TIME_LAUNCHES=1 in the environment (read per call) every launch gets its own pair — kind 0 the history
- * GEMM, 11 layer 0, 10 + 2d / 11 + 2d the statistics / cut of layer d — at 2 - 14 % of the search's wall time. */
+ * GEMM, 11 layer 0, 10 + 2d / 11 + 2d the statistics / cut of layer d — at 2 - 14 % of the search's wall time.
+ * Kind 30: the general-rows scorer (dm_din_forward, JTM child weights: dm_din_rows_split*_kernel), one pair per launch. */
 int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *total_ms);
 /* name (with template arguments) of the kernel that ran the last TDM / OTM beam search, as a profiler lists it
  * (owned by the handle, valid until the next search) */

@@ -228,6 +228,7 @@ def test_split_history_gemm_vs_fp32_gemm():
 def test_split_scorer_by_name_is_refused_where_the_split_gemm_does_not_exist():
     """E = 32 (not a multiple of 64): no split planes are built, DM_SCORER_AUTO runs the fp32 GEMM — and asking for SPLIT_F16 by name is
     DM_ERR_UNSUPPORTED, not a silent fp32 run; E = 1088 (> 1024) pads histories with a zero block as long as a row's records."""
+    from dismember_amd.engine import DismemberError
     eng, orc, w, rng = make(50, 2, 6, 32, 400, 19, np.float32, scale=0.1, with_paths=False)
     seqs = histories(rng, 8, 6, 400)
     eng.set_scorer_mode("auto")

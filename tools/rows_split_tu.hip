@@ -8,3 +8,4 @@
 #include "../dismember_amd/csrc/beam_kernel.hip.inc"
 #include "../dismember_amd/csrc/rows_kernel.hip.inc"
 template __global__ void dm_din_rows_split_kernel<128>(RowsSplitParams);
+template __global__ void dm_din_rows_split_l_kernel<128, 10>(RowsSplitParams);
