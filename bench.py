@@ -139,7 +139,7 @@ def parse():
     ap.add_argument("--other-scorer", type=int, default=1, help="also time the OTHER scorer arithmetic on the same engine and inputs (0 = skip)")
     ap.add_argument("--recall-users", type=int, default=1024, help="users for recall@topk vs brute force (0 skip)")
     ap.add_argument("--diverse", type=int, default=1, help="also time the headline search on beams that DIVERGE (attention path x1.7, embeddings x32) and on an iid (rho 0) table; 0 = skip")
-    ap.add_argument("--long-history", type=int, default=1, help="also time the headline search with 24-position histories (fused two-key-tile kernel vs the per-level pipeline); 0 = skip")
+    ap.add_argument("--long-history", type=int, default=1, help="also time the headline search with 24-position histories (fused two-key-tile kernel); 0 = skip")
     ap.add_argument("--host-buffer-steps", type=int, default=3, help="steps of the headline workload through the host-buffer entry point (0 = skip)")
     ap.add_argument("--jtm-full", type=int, default=1, help="also time the FULL JTM.optimize over the 10M-item catalogue (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--jtm-rows", type=int, default=4, help="training rows per item of the full JTM.optimize extra")
@@ -676,24 +676,17 @@ def main():
         d_s24 = eng.dev_alloc(U2_ * L2_ * 4)
         eng.h2d(d_s24, seqs24)
         long_hist = {"seq_len": L2_, "users_per_step": U2_, "what": "the headline tree, table and beam with 24-position histories, device-resident request"}
-        for key, envv in (("fused", None), ("per_level_pipeline", "1")):
-            if envv is None: os.environ.pop("DM_LONG_PIPELINE", None)
-            else: os.environ["DM_LONG_PIPELINE"] = envv
-            eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
-            sync()
-            n24 = 3 if envv is None else 1
-            t0 = time.perf_counter()
-            for _ in range(n24):
-                eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
-            sync()
-            dt24 = (time.perf_counter() - t0) / n24
-            long_hist[key] = {"kernel": eng.last_beam_kernel(), "ms_per_step": dt24 * 1e3, "users_per_s": U2_ / dt24, "scored_rows": eng.last_scored_rows()}
-            if envv is None:
-                i24 = np.empty((U2_, a.topk), np.int32); eng.d2h(i24, d_ids)
-            else:
-                j24 = np.empty((U2_, a.topk), np.int32); eng.d2h(j24, d_ids)
-                long_hist["identical_id_lists_fused_vs_pipeline"] = "%d/%d" % (int((i24 == j24).all(axis=1).sum()), U2_)
+        # (the per-level pipelines of tdm_pipeline.hip.inc / otm64.hip.inc are a TEST cross-check since round 6 — DM_LONG_PIPELINE=1, tests/test_gpu_edges.py —
+        #  never selected by dispatch and no longer timed here)
         os.environ.pop("DM_LONG_PIPELINE", None)
+        eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.tdm_beam_search_dev(d_s24, U2_, L2_, a.beam, a.topk, d_ids, d_sc, d_cnt)
+        sync()
+        dt24 = (time.perf_counter() - t0) / 3
+        long_hist["fused"] = {"kernel": eng.last_beam_kernel(), "ms_per_step": dt24 * 1e3, "users_per_s": U2_ / dt24, "scored_rows": eng.last_scored_rows()}
         long_hist["fused_over_headline_rate"] = long_hist["fused"]["users_per_s"] / (U * a.steps / dt)      # (per GPU, L = 24 against the headline L)
         eng.dev_free(d_s24)
         eng.tdm_beam_search_dev(d_seq, U, L, a.beam, a.topk, d_ids, d_sc, d_cnt)      # (restore shard 0's results in the output buffers)
