@@ -184,6 +184,7 @@ struct dm_ctx {
   int32_t *d_jtm_rseq = nullptr;       // the rows' history CODES [rows][L] and pad masks [rows] (built once per cached catalogue and id map:
   unsigned *d_jtm_rmask = nullptr;     //  they do not change between the gap steps unless the ancestors are taken per level — hierarchical mode)
   uint64_t jtm_rseq_ids_epoch = 0;     // id-map generation the codes were built from
+  int64_t jtm_rseq_num_index = 0;      // ... and the table size they were bounds-checked against
   std::vector<int64_t> jtm_off;
   int64_t jtm_i_lo = 0, jtm_i_hi = 0, jtm_R_base = 0;      // the items whose rows are on this device (dm_jtm_cache_rows_range) and their first row
   int jtm_L = 0;

@@ -20,3 +20,4 @@ template __global__ void dm_train_rows_kernel<double, 128, 16>(TrainParamsT<doub
 template __global__ void dm_train_rows_kernel<double, 128, 2>(TrainParamsT<double>);
 template __global__ void dm_train_rows_kernel<double, 128, 8>(TrainParamsT<double>);
 template __global__ void dm_train_rows_kernel<float, 128, 16>(TrainParamsT<float>);
+template __global__ void dm_train_rows_kernel<double, 128, DM_MAXL, true>(TrainParamsT<double>);
