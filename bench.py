@@ -1460,10 +1460,13 @@ def main():
             m1 = TDM(e1, "din")
             for _ in range(10):
                 m1.recommend(q1, 10, 20)
-            t0 = time.perf_counter()
-            for _ in range(100):
-                recs1 = m1.recommend(q1, 10, 20)
-            dt1 = (time.perf_counter() - t0) / 100
+            blocks1 = []                     # five blocks of 100 calls, the MEDIAN block reported: late in a long bench run one block can eat a
+            for _b in range(5):              # scheduler stall of the whole process (round 6: 0.74 ms per call in one block, 0.06 in every other setting)
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    recs1 = m1.recommend(q1, 10, 20)
+                blocks1.append((time.perf_counter() - t0) / 100)
+            dt1 = float(np.median(blocks1))
             ot1 = po.TdmTree(t1["codes"], t1["ids"], t1["is_leaf"], t1["leaf_ids"], t1["leaf_codes"], t1["max_level"]); od1 = po.Din(w1, 16, 10, 8191)
             ot1.recommend(od1, q1, 10, 20)
             t0 = time.perf_counter()
@@ -1481,7 +1484,7 @@ def main():
                                                                  for u in range(len(q1s))]))
             c1 = {"workload": "BASELINE configs[0] serving timer: bundled trained E=16 DIN + depth-12 tree (3706 items), TDM.recommend(query, topk=10, "
                               "candidateNum=20), one user per call, 10 warm-up + 100 timed calls",
-                  "ms_per_call": dt1 * 1e3, "cpu_oracle_ms_per_call": dto1 * 1e3, "cpu_oracle": "oracle/libdm_oracle.so, 1 thread",
+                  "ms_per_call": dt1 * 1e3, "ms_per_call_blocks_of_100": [b_ * 1e3 for b_ in blocks1], "cpu_oracle_ms_per_call": dto1 * 1e3, "cpu_oracle": "oracle/libdm_oracle.so, 1 thread",
                   "same_items_as_oracle": sorted(r_[0] for r_ in recs1) == sorted(oi1.tolist()),
                   "recall_vs_bruteforce_trained_model": dict(rec1, users=len(q1s),
                                                              definition="|beam top-k  ∩  brute-force top-k| / k on the bundled trained DIN (tests/golden/din_f32.npy)")}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): round-5 profile set.  Outputs under gpurun_out/prof_<tag>/; tools/summarize_profiles.py condenses
+# Run on the GPU box (via gpurun): round-6 profile set.  Outputs under gpurun_out/prof_<tag>/; tools/summarize_profiles.py condenses
 # them into profiles/.
 #   (1) kernel-trace stats of the WHOLE default bench line (every kernel of every extra: beam, fp64 beam, rows, train, wgrad, Adam,
 #       JTM expand / sum, sampler, Deep-Retrieval)                                                   -> prof_r06_all
@@ -25,7 +25,7 @@ pmc_set() {   # $1 = out dir, rest = command
 HEAD="--steps 4 --warmup 1 --cpu-users 0 --recall-users 0 --small 0 --train 0 --dr 0 --other-scorer 0 --otm64 0 --diverse 0 --long-history 0 --host-buffer-steps 0 --jtm-full 0"
 if [ "$WHAT" = all ] || [ "$WHAT" = full ]; then
   mkdir -p gpurun_out/prof_r06_all
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r06_all/trace -o t -- python bench.py --steps 6 --warmup 1 --cpu-users 0 > gpurun_out/prof_r06_all/bench_trace.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r06_all/trace -o t -- python bench.py --steps 6 --warmup 1 --cpu-users 0 --trained-recall-steps 200 > gpurun_out/prof_r06_all/bench_trace.log 2>&1
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = head ]; then pmc_set gpurun_out/prof_r06 python bench.py $HEAD; fi
 if [ "$WHAT" = all ] || [ "$WHAT" = f32 ]; then pmc_set gpurun_out/prof_r06_f32 python bench.py $HEAD --scorer f32; fi
