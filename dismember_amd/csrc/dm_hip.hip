@@ -895,9 +895,18 @@ int dm_fill_normal_f64(dm_handle_t h, double *d_ptr, int64_t n, float mean, floa
   return DM_OK;
 }
 
+static bool fwd64_ready(dm_ctx *h, int L);                 // train_host.hip.inc
+static int rows_fwd64(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B, int L, double *d_out);
 template <typename T>
 static int din_forward_t(dm_ctx *h, const int32_t *d_codes, const int32_t *d_seqs, const unsigned *d_rowmask, int64_t B,
                          int L, T *d_out) {
+  if constexpr (sizeof(T) == 8) {
+    // f64 models, batches of rows: the matrix-pipe forward (train_host.hip.inc: rows_fwd64 — the training kernel's forward half on
+    // v_mfma_f64_16x16x4_f64) instead of the one-wave-per-row kernel below, which stays for single rows and for clones
+    // (round 6: 34 M rows/s -> 10x; dm_din_forward, OTM child weights, evaluators).  DM_FWD64_SCALAR=1 keeps the scalar kernel.
+    static const bool scalar_only = [] { const char *e_ = getenv("DM_FWD64_SCALAR"); return e_ && e_[0] == '1'; }();
+    if (!scalar_only && B >= 256 && fwd64_ready(h, L)) return rows_fwd64(h, d_codes, d_seqs, d_rowmask, B, L, (double *)d_out);
+  }
   DinFwdParams<T> p;
   const T *base = (const T *)h->d_compact;
   const int E = h->embed;
