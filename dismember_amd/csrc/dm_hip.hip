@@ -73,7 +73,8 @@ struct dm_ctx {
   std::atomic<int> n_clones{0};
   std::atomic<uint64_t> model_epoch{1};
   uint64_t seen_epoch = 0;
-  uint64_t ids_epoch = 1;      // generation of the id maps (dm_load_id_maps)
+  uint64_t ids_epoch = 1;      // generation of the id maps (dm_load_id_maps) and the tree bitmaps (dm_load_tree_tdm)
+  uint64_t seen_ids_epoch = 0; // clone: the owner's generation its host copies were taken at
   std::recursive_mutex mu;
   // tree (codeNodeMap as bitmaps + dense node-id array)
   bool tree_loaded = false, ids_loaded = false, leaves_at_max_only = true;
@@ -444,8 +445,11 @@ static void clone_mirror(dm_ctx *c, dm_ctx *p) {
 #define X(f) c->f = p->f;
   DM_SHARED_FIELDS(X)
 #undef X
-  c->h_id_to_code = p->h_id_to_code;
-  c->h_exists = p->h_exists;
+  if (c->seen_ids_epoch != p->ids_epoch || c->h_exists.size() != p->h_exists.size()) {      // (host vectors: O(catalogue), copied when the tree / id maps changed, not after every Adam step)
+    c->h_id_to_code = p->h_id_to_code;
+    c->h_exists = p->h_exists;
+    c->seen_ids_epoch = p->ids_epoch;
+  }
   c->emb32_owned = false;
   // the parent's copies were brought up to date before the mirror was taken: nothing is stale for the clone, and nothing is rebuilt by it
   c->split_dirty = false; c->emb_split_dirty = false; c->rows_split_dirty = false; c->frag64_dirty = false; c->f32_mirror_dirty = false;
@@ -573,6 +577,7 @@ int dm_load_tree_tdm(dm_handle_t h, const int32_t *codes, const int32_t *node_id
   if (!leaf_codes.empty())
     HIPCHK(h, hipMemcpy(h->d_leaf_codes, leaf_codes.data(), leaf_codes.size() * 4, hipMemcpyHostToDevice));
   h->h_exists = ex;
+  h->ids_epoch++;              // (clones re-copy their host vectors; per-row code caches built against the old tree are dropped)
   h->n_slots = n_slots; h->n_leaf_nodes = (int64_t)leaf_codes.size(); h->max_level = max_level;
   h->leaves_at_max_only = at_max_only; h->tree_loaded = true;
   return DM_OK;
@@ -2127,12 +2132,13 @@ int dm_kernel_timing_get(dm_handle_t h, int *launches, double *total_ms) {
   if (!h || !launches || !total_ms) return DM_ERR_INVALID;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double tot = 0;
+  int n = 0;
   for (size_t i = 0; i < h->ev_used; i++) {
     float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
-    tot += ms;
+    if (hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }     // (see dm_kernel_timing_get_kind)
+    tot += ms; n++;
   }
-  *launches = (int)h->ev_used; *total_ms = tot;
+  *launches = n; *total_ms = tot;
   return DM_OK;
 }
 const char *dm_last_beam_kernel(dm_handle_t h) { return h ? h->last_kernel : ""; }
@@ -2144,7 +2150,8 @@ int dm_kernel_timing_get_kind(dm_handle_t h, int kind, int *launches, double *to
   for (size_t i = 0; i < h->ev_used; i++) {
     if (h->ev_kind[i] != kind) continue;
     float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+    // (a pair whose stop event was never recorded — a call that failed between its two records — is skipped, not an error of this query)
+    if (hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }
     tot += ms; n++;
   }
   *launches = n; *total_ms = tot;
