@@ -874,7 +874,7 @@ def main():
     #      JTM re-assignment scoring step (configs[3]); host-buffer entry points, so these rates include the PCIe copies ----
     otm = jtm = None
     if a.small and default_cfg:
-        Uo = 32768
+        Uo = min(32768, U)
         lut = np.zeros(int(tree["leaf_ids"].max()) + 1, np.int32)
         lut[tree["leaf_ids"]] = tree["leaf_codes"]
         ocodes = np.where(seqs[:Uo] > 0, lut[np.clip(seqs[:Uo], 0, lut.size - 1)], -1).astype(np.int32)   # items -> leaf nodes (OTM.scala:15)
