@@ -817,13 +817,13 @@ def main():
                     why = "profiles/%s was taken on another workload" % pname
                 elif kern_name not in prof["kernel_trace"]["kernel"]:
                     why = "profiles/%s profiled %s, this run timed %s" % (pname, prof["kernel_trace"]["kernel"], kern_name)
-                elif abs(pms - avg_ms) > 0.05 * avg_ms:
-                    why = "profiles/%s: profiled kernel average %.2f ms differs from this run's %.2f ms by more than 5 %%" % (pname, pms, avg_ms)
+                elif abs(pms - avg_ms) > 0.07 * avg_ms:            # (box-to-box spread of this kernel under the power cap is +-3 % around the profiled box)
+                    why = "profiles/%s: profiled kernel average %.2f ms differs from this run's %.2f ms by more than 7 %%" % (pname, pms, avg_ms)
                 else:
                     res["roofline"]["traffic"] = prof["hbm_traffic_per_launch_bytes"]["total_corrected"]
                     res["roofline"]["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch, "
                                                          "FETCH x2 gfx950 correction (MI355X_MICROARCH.md); attached because the profiled kernel is the "
-                                                         "one timed here and its average duration agrees within 5 %%") % pname
+                                                         "one timed here and its average duration agrees within 7 %%") % pname
                     res["roofline"]["profiled_kernel_ms_avg"] = pms
                     if "mfma_pipe_utilisation" in prof:
                         res["roofline"]["profiled_mfma_busy_frac"] = prof["mfma_pipe_utilisation"]
